@@ -1,0 +1,149 @@
+/*
+ * psascan_amd.h -- C ABI of the MI355X-native streaming-gap + merge path of pSAscan.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its
+ * `process_block` (include/partial_sufsort.hpp:67-551) and `pSAscan`
+ * (include/psascan.hpp:53-131) call a handful of C++ templates with raw pointers.
+ * Each entry point below replaces one of those call sites; the cited file:line is
+ * relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all sizes/positions are int64_t.
+ *   - `d_` pointers are device (HBM) pointers, `h_` pointers are host pointers.
+ *   - every function returns 0 on success, a negative PSG_E* code otherwise, never
+ *     exits or throws; psg_last_error() describes the last failure of the calling thread.
+ *   - bit arrays are little-endian arrays of uint32_t, LSB-first (bit i = word i/32,
+ *     bit i%32) -- byte-identical to the reference's bitvector (bitvector.hpp:61-67).
+ *   - a "gt" bit array that belongs to the position range (lo, hi] stores the bit of text
+ *     position j at index u = hi - j.  This is the reference's reversed indexing (bit n-j
+ *     of the multifile, compute_gap.hpp:118-119, stream.hpp:104-106) shifted by n-hi.
+ *   - one host thread drives one device; work is enqueued on the library's stream and the
+ *     call returns after the result is complete unless stated otherwise.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef PSASCAN_AMD_H
+#define PSASCAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSG_OK 0
+#define PSG_EINVAL (-1)   /* bad argument                                  */
+#define PSG_EDEVICE (-2)  /* HIP runtime error / no device                 */
+#define PSG_ENOMEM (-3)   /* device allocation failed                      */
+#define PSG_EOVERFLOW (-4)/* a u32 gap counter would overflow              */
+#define PSG_ECHECK (-5)   /* an internal invariant check failed            */
+
+/* ---- runtime ------------------------------------------------------------------------ */
+int psg_init(int device);                 /* select device, create the stream            */
+const char *psg_last_error(void);
+int psg_device_name(char *buf, int cap);
+int psg_malloc(void **d_ptr, int64_t bytes);
+int psg_free(void *d_ptr);
+int psg_memset(void *d_ptr, int value, int64_t bytes);
+int psg_h2d(void *d_dst, const void *h_src, int64_t bytes);
+int psg_d2h(void *h_dst, const void *d_src, int64_t bytes);
+int psg_d2d(void *d_dst, const void *d_src, int64_t bytes);
+int psg_sync(void);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int psg_set_stream(void *hip_stream);
+
+/* ---- rank over a block BWT: replaces `new rank4n<>(bwt, m, threads)`,
+ *      partial_sufsort.hpp:403,500 ; semantics rank.hpp:566-568, m_count rank.hpp:112 --- */
+typedef struct psg_rank psg_rank_t;
+/* data_bytes_per_block: 0 = choose from the alphabet (64, or 48 when sigma <= 4).        */
+int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes_per_block, psg_rank_t **out);
+int psg_rank_counts(const psg_rank_t *r, int64_t counts[256]);
+int64_t psg_rank_device_bytes(const psg_rank_t *r);
+/* batch query, used by the parity tests: out[k] = rank(i[k], c[k])                      */
+int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uint8_t *d_c, int64_t nq, int64_t *d_out);
+void psg_rank_free(psg_rank_t *r);
+
+/* ---- one streaming pass: replaces compute_gap<T>(...), partial_sufsort.hpp:412-414 and
+ *      :512-514 (compute_gap.hpp:61-157 -> stream.hpp:147-158 + update.hpp:86-96) -------
+ *  d_tail           text[tail_begin .. tail_end)               (tail_len bytes)
+ *  d_gt_in          gt of positions (tail_begin, tail_end] w.r.t. the END of the block the
+ *                   rank was built on; bit u <-> position tail_end - u; NULL = all zero
+ *  rank_at_tail_end number of block suffixes smaller than text[tail_end..n)
+ *                   (the reference's initial_ranks.back(), stream.hpp:66,108)
+ *  d_gap            m+1 uint32 counters, INCREMENTED (zero them first for a fresh array);
+ *                   value semantics of buffered_gap_array (gap_array.hpp:116-124)
+ *  d_gt_out         tail_len bits written: bit u = [text[tail_end-u..n) > text[block_beg..n)]
+ *                   (stream.hpp:150); may be NULL
+ *  max_chains       0 = auto (fill the chip); the tail is cut into that many independent
+ *                   backward-search chains whose start ranks are found on the device
+ *  h_final_rank     out: rank of text[tail_begin..n) among the block suffixes; may be NULL
+ */
+typedef struct {
+  int64_t n_chains;        /* chains actually used                                  */
+  int64_t chain_len;       /* steps per chain                                       */
+  int64_t warmup_steps;    /* warm-up steps per chain boundary (last attempt)       */
+  int64_t unresolved;      /* chain starts that needed the sequential fallback      */
+  int64_t rounds;          /* stream kernel launches                                */
+  double kernel_ms;        /* time of the stream kernel launches (HIP events)       */
+  double total_ms;         /* whole call                                            */
+} psg_stream_stats;
+
+int psg_stream_gap(const psg_rank_t *rank, int64_t block_i0, int block_last_symbol,
+                   const uint8_t *d_tail, int64_t tail_len, const uint32_t *d_gt_in,
+                   int64_t rank_at_tail_end, uint32_t *d_gap, uint32_t *d_gt_out,
+                   int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats);
+
+/* ---- buffered_gap_array::convert_to_bitvector, partial_sufsort.hpp:441
+ *      (gap_array.hpp:273-364): for j=0..m: gap[j] ones, then a zero (none after j=m).
+ *      d_bv needs room for m + sum(gap) bits rounded up to 32; *nbits = m + sum(gap). ---- */
+int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *d_bv, int64_t bv_capacity_bits,
+                         int64_t *nbits);
+
+/* ---- merge_bwt, partial_sufsort.hpp:470-471 (bwt_merge.hpp:66-140) --------------------- */
+int psg_merge_bwt(const uint8_t *d_left_bwt, const uint8_t *d_right_bwt, int64_t ml, int64_t mr,
+                  int64_t left_i0, int64_t right_i0, int left_last_symbol, const uint32_t *d_bv,
+                  uint8_t *d_out_bwt, int64_t *block_i0);
+
+/* ---- compute_right_gap + compute_left_gap, partial_sufsort.hpp:541-542
+ *      (compute_right_gap.hpp:161-305, compute_left_gap.hpp:162-306, gap_array_2n
+ *      gap_array.hpp:386-529).  The half-block gaps are produced in their unary
+ *      ("merge bitvector") form, which is what psg_merge consumes:
+ *        mbv = for r = 0..size: gap[r] ones, then (r < size) a zero.
+ *      d_mbv_left  : ml + mr + tail_len bits,  d_mbv_right : mr + tail_len bits.
+ *      tail_len must equal sum(d_block_gap) (checked).                               ---- */
+int psg_split_gap(const uint32_t *d_block_gap, const uint32_t *d_bv, int64_t ml, int64_t mr,
+                  int64_t tail_len, uint32_t *d_mbv_left, uint32_t *d_mbv_right);
+
+/* gap values (what the reference writes to its .gap files) out of a merge bitvector.      */
+int psg_mbv_to_gap(const uint32_t *d_mbv, int64_t nbits, int64_t size, uint64_t *d_gap_out /* size+1 */);
+/* vbyte codec of the gap files (utils/parallel_utils.hpp:47-136;
+ * io/async_vbyte_stream_reader.hpp:49-186): replaces save_to_file, partial_sufsort.hpp:422 */
+int psg_vbyte_encode(const uint64_t *d_vals, int64_t count, uint8_t *d_out, int64_t capacity, int64_t *nbytes);
+
+/* ---- merge<T>, psascan.hpp:120,124 (merge.hpp:55-180) ---------------------------------
+ *  Half-blocks sorted by beg.  psa = positions relative to beg, low 32 bits (+ optional
+ *  high byte array for half-blocks larger than 2^32).  d_mbv = NULL for the last one.
+ *  Output: entries [out_begin, out_begin+out_count) of the suffix array as 40-bit
+ *  little-endian integers (types/uint40.hpp:42-104), 5*out_count bytes at d_out_sa5.      */
+typedef struct {
+  int64_t beg, size;
+  const uint32_t *d_psa_lo;
+  const uint8_t *d_psa_hi;   /* may be NULL */
+  const uint32_t *d_mbv;     /* size + (sizes of all later half-blocks) bits; NULL for last */
+} psg_hb_desc;
+typedef struct psg_merge_plan psg_merge_plan_t;
+int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out);
+int psg_merge_run(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint8_t *d_out_sa5);
+void psg_merge_plan_free(psg_merge_plan_t *plan);
+
+/* ---- small device utilities the host orchestration needs ------------------------------ */
+/* dst bits [dst_bit, dst_bit+nbits) = src bits [src_bit, src_bit+nbits) (non-overlapping) */
+int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t src_bit, int64_t nbits);
+/* number of one bits in [0, nbits)                                                        */
+int psg_popcount(const uint32_t *d_bits, int64_t nbits, int64_t *ones);
+/* timing of the last kernel sequence of the named entry point, in ms (HIP events)          */
+double psg_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSASCAN_AMD_H */

@@ -1,0 +1,90 @@
+"""ctypes loader of libpsascan_hip.so (C ABI: include/psascan_amd.h)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpsascan_hip.so")
+
+
+class PsgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"psascan_amd error {code}: {msg}")
+        self.code = code
+
+
+class StreamStatsC(C.Structure):
+    _fields_ = [("n_chains", C.c_int64), ("chain_len", C.c_int64), ("warmup_steps", C.c_int64), ("unresolved", C.c_int64),
+                ("rounds", C.c_int64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class HbDescC(C.Structure):
+    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p)]
+
+
+# every symbol include/psascan_amd.h declares: name -> (restype, argtypes)
+_vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
+SIGNATURES = {
+    "psg_init": (_int, [_int]),
+    "psg_last_error": (C.c_char_p, []),
+    "psg_device_name": (_int, [C.c_char_p, _int]),
+    "psg_malloc": (_int, [C.POINTER(_vp), _i64]),
+    "psg_free": (_int, [_vp]),
+    "psg_memset": (_int, [_vp, _int, _i64]),
+    "psg_h2d": (_int, [_vp, _vp, _i64]),
+    "psg_d2h": (_int, [_vp, _vp, _i64]),
+    "psg_d2d": (_int, [_vp, _vp, _i64]),
+    "psg_sync": (_int, []),
+    "psg_set_stream": (_int, [_vp]),
+    "psg_rank_build": (_int, [_vp, _i64, _int, C.POINTER(_vp)]),
+    "psg_rank_counts": (_int, [_vp, C.POINTER(_i64)]),
+    "psg_rank_device_bytes": (_i64, [_vp]),
+    "psg_rank_query": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "psg_rank_free": (None, [_vp]),
+    "psg_stream_gap": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_gap_to_bitvector": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "psg_merge_bwt": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, C.POINTER(_i64)]),
+    "psg_split_gap": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "psg_mbv_to_gap": (_int, [_vp, _i64, _i64, _vp]),
+    "psg_vbyte_encode": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "psg_merge_plan_create": (_int, [C.POINTER(HbDescC), _int, C.POINTER(_vp)]),
+    "psg_merge_run": (_int, [_vp, _i64, _i64, _vp]),
+    "psg_merge_plan_free": (None, [_vp]),
+    "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
+    "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),
+    "psg_last_kernel_ms": (C.c_double, []),
+}
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the HIP library and bind every declared symbol (no device needed)."""
+    if not os.path.exists(path):
+        raise PsgError(-2, f"{path} not found -- run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
+                           "psascan_amd has no CPU fallback")
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)   # AttributeError if the symbol is missing
+        f.restype = res
+        f.argtypes = args
+    return L
+
+
+_LIB = None
+
+
+def lib(device=None):
+    """The initialised library; raises PsgError when no HIP device is available."""
+    global _LIB
+    if _LIB is None:
+        L = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        rc = L.psg_init(device)
+        if rc != 0:
+            raise PsgError(rc, L.psg_last_error().decode())
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise PsgError(rc, _LIB.psg_last_error().decode() if _LIB else "library not initialised")

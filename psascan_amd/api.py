@@ -1,0 +1,215 @@
+"""Python mirror of the C ABI (include/psascan_amd.h).  Names follow the reference's call sites
+(partial_sufsort.hpp:403-542, psascan.hpp:120): rank_build ~ `new rank4n<>`, stream_gap ~
+`compute_gap<T>`, gap_to_bitvector ~ `convert_to_bitvector`, merge_bwt, split_gap ~
+`compute_right_gap`+`compute_left_gap`, merge_half_blocks ~ `merge<T>`.  Everything runs on the
+device; numpy arrays are only the host ends of explicit upload()/download()."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HbDescC, StreamStatsC, check, lib
+
+
+class DeviceBuffer:
+    """Owning handle of a device allocation (HBM)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().psg_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().psg_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def at(self, byte_offset):
+        return self.ptr + int(byte_offset)
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return int(x)
+
+
+def sync():
+    check(lib().psg_sync())
+
+
+def zeros(nbytes):
+    b = DeviceBuffer(nbytes)
+    check(lib().psg_memset(b.ptr, 0, b.nbytes))
+    return b
+
+
+def upload(arr, pad_to=4):
+    """numpy -> new device buffer (size rounded up to `pad_to` bytes, padding zeroed)."""
+    a = np.ascontiguousarray(arr)
+    nb = a.nbytes
+    cap = (nb + pad_to - 1) // pad_to * pad_to
+    b = zeros(max(cap, pad_to))
+    if nb:
+        check(lib().psg_h2d(b.ptr, a.ctypes.data, nb))
+    return b
+
+
+def download(buf, dtype, count, byte_offset=0):
+    out = np.empty(int(count), dtype)
+    if out.nbytes:
+        check(lib().psg_d2h(out.ctypes.data, _ptr(buf) + byte_offset, out.nbytes))
+    return out
+
+
+class RankStructure:
+    """Device-resident rank over a block BWT (reference: rank4n<>, rank.hpp:74-722)."""
+
+    def __init__(self, handle, m):
+        self.h = handle
+        self.m = m
+        cnt = (C.c_int64 * 256)()
+        check(lib().psg_rank_counts(self.h, cnt))
+        self.counts = np.array(cnt[:], np.int64)
+
+    def device_bytes(self):
+        return lib().psg_rank_device_bytes(self.h)
+
+    def query(self, i, c):
+        i = np.ascontiguousarray(i, np.int64)
+        c = np.ascontiguousarray(c, np.uint8)
+        di, dc, do = upload(i), upload(c), DeviceBuffer(max(8, i.nbytes))
+        check(lib().psg_rank_query(self.h, di.ptr, dc.ptr, len(i), do.ptr))
+        return download(do, np.int64, len(i))
+
+    def free(self):
+        if self.h:
+            lib().psg_rank_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def rank_build(d_bwt, m, data_bytes_per_block=0):
+    h = C.c_void_p()
+    check(lib().psg_rank_build(_ptr(d_bwt), m, data_bytes_per_block, C.byref(h)))
+    return RankStructure(h.value, m)
+
+
+class StreamStats:
+    def __init__(self, s):
+        for k, _ in StreamStatsC._fields_:
+            setattr(self, k, getattr(s, k))
+
+    def __repr__(self):
+        return "StreamStats(" + ", ".join(f"{k}={getattr(self, k)}" for k, _ in StreamStatsC._fields_) + ")"
+
+
+def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_tail_end, d_gap, d_gt_out,
+               max_chains=0):
+    """One streaming pass (compute_gap<T>).  Returns (final_rank, StreamStats)."""
+    fin = C.c_int64(0)
+    st = StreamStatsC()
+    check(lib().psg_stream_gap(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, _ptr(d_gt_in),
+                               rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains, C.byref(fin), C.byref(st)))
+    return fin.value, StreamStats(st)
+
+
+def gap_to_bitvector(d_gap, m, d_bv, capacity_bits):
+    nbits = C.c_int64(0)
+    check(lib().psg_gap_to_bitvector(_ptr(d_gap), m, _ptr(d_bv), capacity_bits, C.byref(nbits)))
+    return nbits.value
+
+
+def merge_bwt(d_left_bwt, d_right_bwt, ml, mr, left_i0, right_i0, left_last, d_bv, d_out):
+    bi0 = C.c_int64(-1)
+    check(lib().psg_merge_bwt(_ptr(d_left_bwt), _ptr(d_right_bwt), ml, mr, left_i0, right_i0, int(left_last), _ptr(d_bv),
+                              _ptr(d_out), C.byref(bi0)))
+    return bi0.value
+
+
+def split_gap(d_block_gap, d_bv, ml, mr, tail_len, d_mbv_left, d_mbv_right):
+    check(lib().psg_split_gap(_ptr(d_block_gap), _ptr(d_bv), ml, mr, tail_len, _ptr(d_mbv_left), _ptr(d_mbv_right)))
+
+
+def mbv_to_gap(d_mbv, nbits, size):
+    out = DeviceBuffer(8 * (size + 1))
+    check(lib().psg_mbv_to_gap(_ptr(d_mbv), nbits, size, out.ptr))
+    return out
+
+
+def vbyte_encode(d_vals, count):
+    out = DeviceBuffer(10 * count + 16)
+    nb = C.c_int64(0)
+    check(lib().psg_vbyte_encode(_ptr(d_vals), count, out.ptr, out.nbytes, C.byref(nb)))
+    return out, nb.value
+
+
+class MergePlan:
+    """half_blocks: list of dicts {beg, size, psa_lo, psa_hi (or None), mbv (or None for the last)}."""
+
+    def __init__(self, half_blocks):
+        H = len(half_blocks)
+        arr = (HbDescC * H)()
+        for k, hb in enumerate(half_blocks):
+            arr[k].beg = hb["beg"]
+            arr[k].size = hb["size"]
+            arr[k].d_psa_lo = _ptr(hb["psa_lo"])
+            arr[k].d_psa_hi = _ptr(hb.get("psa_hi"))
+            arr[k].d_mbv = _ptr(hb.get("mbv"))
+        self._keep = half_blocks
+        self.n = sum(hb["size"] for hb in half_blocks)
+        h = C.c_void_p()
+        check(lib().psg_merge_plan_create(arr, H, C.byref(h)))
+        self.h = h.value
+
+    def run(self, out_begin, out_count, d_out):
+        check(lib().psg_merge_run(self.h, out_begin, out_count, _ptr(d_out)))
+
+    def free(self):
+        if getattr(self, "h", None):
+            lib().psg_merge_plan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def merge_half_blocks(half_blocks, d_out=None):
+    """merge<T>: whole suffix array as uint40 LE into a device buffer (returned)."""
+    plan = MergePlan(half_blocks)
+    if d_out is None:
+        d_out = DeviceBuffer(5 * plan.n + 8)
+    plan.run(0, plan.n, d_out)
+    plan.free()
+    return d_out
+
+
+def bitcopy(d_dst, dst_bit, d_src, src_bit, nbits):
+    check(lib().psg_bitcopy(_ptr(d_dst), dst_bit, _ptr(d_src), src_bit, nbits))
+
+
+def popcount(d_bits, nbits):
+    v = C.c_int64(0)
+    check(lib().psg_popcount(_ptr(d_bits), nbits, C.byref(v)))
+    return v.value
+
+
+def last_kernel_ms():
+    return lib().psg_last_kernel_ms()

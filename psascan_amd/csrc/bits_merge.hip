@@ -1,0 +1,497 @@
+// bits_merge.hip -- K3 gap->bitvector, K4 BWT merge, K5 gap split (unary / "merge
+// bitvector" form), K6 gap values + vbyte, K7 final merge.  All are tile-scan + scatter:
+//   tile reduce -> single-workgroup scan of the tile sums -> tile apply.
+// Reference loops restated (semantics only): gap_array.hpp:273-364, bwt_merge.hpp:66-140,
+// compute_right_gap.hpp:55-122, compute_left_gap.hpp:55-123, utils/parallel_utils.hpp:47-136,
+// merge.hpp:110-159.
+#include "dev_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+using namespace psg;
+
+#define TILE_V 2048   // values per tile (8 per thread)
+#define TILE_B 4096   // bits / outputs per tile (16 per thread)
+
+// =======================================================================================
+// small kernels shared by several entry points
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void tile_sum_u32_kernel(const u32 *v, i64 n, u64 *tile_sum) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u64 s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (base + q < n) s += v[base + q];
+  u64 tot = block_sum<u64>(s, scratch);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+// ones (or zeros) per TILE_B-bit tile of a bit array of nbits bits
+template <bool ZEROS>
+__global__ __launch_bounds__(PSG_WG) void tile_popc_kernel(const u32 *bv, i64 nbits, u64 *tile_cnt) {
+  __shared__ u64 scratch[8];
+  i64 nwords = (nbits + 31) >> 5;
+  i64 b0 = (i64)blockIdx.x * TILE_B + (i64)threadIdx.x * 16;
+  int n = (int)std::max<i64>(0, std::min<i64>(16, nbits - b0));
+  u32 bits = n > 0 ? get_bits(bv, b0, n, nwords) : 0;
+  u64 c = ZEROS ? (u64)(n - __popc(bits)) : (u64)__popc(bits);
+  u64 tot = block_sum<u64>(c, scratch);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ void mask_tail_kernel(u32 *bv, i64 nbits) {
+  if (nbits & 31) bv[nbits >> 5] &= (1u << (nbits & 31)) - 1u;
+}
+
+static int fill_ones(u32 *d_bv, i64 nbits) {
+  if (nbits <= 0) return 0;
+  PSG_HIP(hipMemsetAsync(d_bv, 0xFF, (size_t)(((nbits + 31) >> 5) * 4), stream()));
+  hipLaunchKernelGGL(mask_tail_kernel, dim3(1), dim3(1), 0, stream(), d_bv, nbits);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
+__device__ __forceinline__ void clear_bit(u32 *bv, i64 pos) { atomicAnd(&bv[pos >> 5], ~(1u << (pos & 31))); }
+
+// =======================================================================================
+// K3: gap -> bitvector
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap, i64 m, const u64 *tile_pref, u32 *bv) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u32 g[8];
+  u64 s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { g[q] = base + q <= m ? gap[base + q] : 0; s += g[q]; }
+  u64 tot;
+  u64 pre = tile_pref[blockIdx.x] + block_excl_scan<u64>(s, scratch, tot);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    pre += g[q];
+    i64 j = base + q;
+    if (j < m) clear_bit(bv, j + (i64)pre);
+  }
+}
+
+extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *d_bv, int64_t cap_bits, int64_t *nbits) {
+  PSG_REQUIRE(d_gap && d_bv && m >= 0 && nbits, "psg_gap_to_bitvector");
+  EventTimer tm; tm.start();
+  i64 n = m + 1, ntiles = cdiv(n, TILE_V);
+  DevBuf ts, tot;
+  int rc;
+  if ((rc = ts.alloc(ntiles * 8)) || (rc = tot.alloc(8))) return rc;
+  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, n, ts.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  u64 total = 0;
+  PSG_HIP(hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  *nbits = m + (i64)total;
+  if (*nbits > cap_bits) { set_error("psg_gap_to_bitvector: output capacity too small"); return PSG_EINVAL; }
+  if ((rc = fill_ones(d_bv, *nbits))) return rc;
+  hipLaunchKernelGGL(gap_to_bv_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, m, ts.as<u64>(), d_bv);
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  note_kernel_ms(tm.ms());
+  return 0;
+}
+
+// =======================================================================================
+// K4: BWT merge
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void merge_bwt_apply_kernel(const u8 *L, const u8 *R, i64 ml, i64 mr, i64 left_i0, i64 right_i0,
+                                                                   u32 left_last, const u32 *bv, const u64 *tile_pref, u8 *out,
+                                                                   i64 *block_i0) {
+  __shared__ u32 scratch[8];
+  __shared__ u8 sL[TILE_B], sR[TILE_B];
+  __shared__ __attribute__((aligned(4))) u8 sO[TILE_B];
+  i64 block = ml + mr, nwords = (block + 31) >> 5;
+  i64 k0 = (i64)blockIdx.x * TILE_B;
+  int nvalid = (int)std::min<i64>(TILE_B, block - k0);
+  int e0 = threadIdx.x * 16;
+  int n = std::max(0, std::min(16, nvalid - e0));
+  u32 bits = n > 0 ? get_bits(bv, k0 + e0, n, nwords) : 0;
+  u32 nr;
+  u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, nr);
+  i64 r0 = (i64)tile_pref[blockIdx.x], l0 = k0 - r0;
+  int nl = nvalid - (int)nr;
+  for (int k = threadIdx.x; k < nl; k += PSG_WG) sL[k] = L[l0 + k];
+  for (int k = threadIdx.x; k < (int)nr; k += PSG_WG) sR[k] = R[r0 + k];
+  __syncthreads();
+  int z = e0 - (int)o;
+  for (int q = 0; q < n; ++q) {
+    u32 bit = (bits >> q) & 1u;
+    int below = __popc(bits & ((1u << q) - 1u));
+    u8 v;
+    if (bit) {
+      int ri = (int)o + below;
+      v = (r0 + ri == right_i0) ? (u8)left_last : sR[ri];       // bwt_merge.hpp:128
+    } else {
+      int li = z + q - below;
+      v = sL[li];
+      if (l0 + li == left_i0) *block_i0 = k0 + e0 + q;           // bwt_merge.hpp:133
+    }
+    sO[e0 + q] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x * 4; k < nvalid; k += PSG_WG * 4) {
+    if (k + 4 <= nvalid) *(u32 *)(out + k0 + k) = *(const u32 *)(sO + k);
+    else for (int q = k; q < nvalid; ++q) out[k0 + q] = sO[q];
+  }
+}
+
+extern "C" int psg_merge_bwt(const uint8_t *d_l, const uint8_t *d_r, int64_t ml, int64_t mr, int64_t left_i0, int64_t right_i0,
+                             int left_last, const uint32_t *d_bv, uint8_t *d_out, int64_t *block_i0) {
+  PSG_REQUIRE(d_l && d_r && d_bv && d_out && block_i0 && ml >= 1 && mr >= 1, "psg_merge_bwt");
+  PSG_REQUIRE(left_i0 >= 0 && left_i0 < ml && right_i0 >= 0 && right_i0 < mr, "psg_merge_bwt: i0 out of range");
+  PSG_REQUIRE(((uintptr_t)d_out & 3) == 0, "psg_merge_bwt: output must be 4-byte aligned");
+  EventTimer tm; tm.start();
+  i64 block = ml + mr, ntiles = cdiv(block, TILE_B);
+  DevBuf tc, tot, bi0;
+  int rc;
+  if ((rc = tc.alloc(ntiles * 8)) || (rc = tot.alloc(8)) || (rc = bi0.alloc(8))) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_bv, block, tc.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(tc.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  u64 ones = 0;
+  PSG_HIP(hipMemcpyAsync(&ones, tot.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if ((i64)ones != mr) { set_error("psg_merge_bwt: bitvector has " + std::to_string(ones) + " ones, expected " + std::to_string(mr)); return PSG_ECHECK; }
+  PSG_HIP(hipMemsetAsync(bi0.p, 0xFF, 8, stream()));
+  hipLaunchKernelGGL(merge_bwt_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_l, d_r, ml, mr, left_i0, right_i0,
+                     (u32)left_last, d_bv, tc.as<u64>(), d_out, bi0.as<i64>());
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(hipMemcpyAsync(block_i0, bi0.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  note_kernel_ms(tm.ms());
+  if (*block_i0 < 0) { set_error("psg_merge_bwt: block_i0 not found"); return PSG_ECHECK; }
+  return 0;
+}
+
+// =======================================================================================
+// K5: split the block gap into the merge bitvectors of the two half-blocks.
+//   PS[k] = sum_{t<=k} block_gap[t];  r1(k) = #ones of bv before k
+//   bv[k]==0 (left suffix)  -> mbv_left  has a zero at k + PS[k]
+//   bv[k]==1 (right suffix) -> mbv_right has a zero at r1(k) + PS[k]
+// (closed form of the segment sums of compute_left_gap.hpp:55-123 /
+//  compute_right_gap.hpp:55-122)
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, const u32 *bv, i64 block, u64 *tile_g, u64 *tile_o) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u64 s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (base + q <= block) s += gap[base + q];
+  int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
+  u32 bits = n > 0 ? get_bits(bv, base, n, (block + 31) >> 5) : 0;
+  u64 tg = block_sum<u64>(s, scratch);
+  u64 to = block_sum<u64>((u64)__popc(bits), scratch);
+  if (threadIdx.x == 0) { tile_g[blockIdx.x] = tg; tile_o[blockIdx.x] = to; }
+}
+
+__global__ __launch_bounds__(PSG_WG) void split_apply_kernel(const u32 *gap, const u32 *bv, i64 block, const u64 *tile_g,
+                                                               const u64 *tile_o, u32 *mbv_left, u32 *mbv_right) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u32 g[8];
+  u64 s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { g[q] = base + q <= block ? gap[base + q] : 0; s += g[q]; }
+  int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
+  u32 bits = n > 0 ? get_bits(bv, base, n, (block + 31) >> 5) : 0;
+  u64 t0, t1;
+  u64 ps = tile_g[blockIdx.x] + block_excl_scan<u64>(s, scratch, t0);
+  u64 r1 = tile_o[blockIdx.x] + block_excl_scan<u64>((u64)__popc(bits), scratch, t1);
+  for (int q = 0; q < n; ++q) {
+    ps += g[q];
+    i64 k = base + q;
+    if ((bits >> q) & 1u) { clear_bit(mbv_right, (i64)(r1 + ps)); ++r1; }
+    else clear_bit(mbv_left, k + (i64)ps);
+  }
+}
+
+extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_t ml, int64_t mr, int64_t tail_len,
+                             uint32_t *d_mbv_left, uint32_t *d_mbv_right) {
+  PSG_REQUIRE(d_gap && d_bv && d_mbv_left && d_mbv_right && ml >= 1 && mr >= 1 && tail_len >= 0, "psg_split_gap");
+  EventTimer tm; tm.start();
+  i64 block = ml + mr, ntiles = cdiv(block + 1, TILE_V);
+  DevBuf tg, to, tot;
+  int rc;
+  if ((rc = tg.alloc(ntiles * 8)) || (rc = to.alloc(ntiles * 8)) || (rc = tot.alloc(16))) return rc;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, d_bv, block, tg.as<u64>(), to.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(tg.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  if ((rc = scan_u64_inplace(to.as<u64>(), ntiles, tot.as<u64>() + 1))) return rc;
+  u64 t[2];
+  PSG_HIP(hipMemcpyAsync(t, tot.p, 16, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if ((i64)t[0] != tail_len) { set_error("psg_split_gap: sum(block_gap)=" + std::to_string(t[0]) + " != tail_len=" + std::to_string(tail_len)); return PSG_ECHECK; }
+  if ((i64)t[1] != mr) { set_error("psg_split_gap: bitvector ones=" + std::to_string(t[1]) + " != right size " + std::to_string(mr)); return PSG_ECHECK; }
+  if ((rc = fill_ones(d_mbv_left, block + tail_len)) || (rc = fill_ones(d_mbv_right, mr + tail_len))) return rc;
+  hipLaunchKernelGGL(split_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, d_bv, block, tg.as<u64>(), to.as<u64>(),
+                     d_mbv_left, d_mbv_right);
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  note_kernel_ms(tm.ms());
+  return 0;
+}
+
+// =======================================================================================
+// K6: merge bitvector -> gap values; vbyte
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void zpos_kernel(const u32 *mbv, i64 nbits, const u64 *tile_pref, u64 *zpos) {
+  __shared__ u32 scratch[8];
+  i64 b0 = (i64)blockIdx.x * TILE_B + (i64)threadIdx.x * 16;
+  int n = (int)std::max<i64>(0, std::min<i64>(16, nbits - b0));
+  u32 bits = n > 0 ? get_bits(mbv, b0, n, (nbits + 31) >> 5) : 0;
+  u32 tot;
+  u32 zr = block_excl_scan<u32>((u32)(n - __popc(bits)), scratch, tot);
+  u64 r = tile_pref[blockIdx.x] + zr;
+  for (int q = 0; q < n; ++q) if (!((bits >> q) & 1u)) zpos[r++] = (u64)(b0 + q);
+}
+__global__ __launch_bounds__(PSG_WG) void zpos_to_gap_kernel(const u64 *zpos, i64 size, i64 nbits, u64 *gap) {
+  i64 r = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (r > size) return;
+  u64 prev_end = r ? zpos[r - 1] + 1 : 0;
+  gap[r] = (r < size ? zpos[r] : (u64)nbits) - prev_end;
+}
+
+extern "C" int psg_mbv_to_gap(const uint32_t *d_mbv, int64_t nbits, int64_t size, uint64_t *d_gap_out) {
+  PSG_REQUIRE(d_mbv && d_gap_out && nbits >= size && size >= 0, "psg_mbv_to_gap");
+  i64 ntiles = std::max<i64>(1, cdiv(nbits, TILE_B));
+  DevBuf tc, tot, zp;
+  int rc;
+  if ((rc = tc.alloc(ntiles * 8)) || (rc = tot.alloc(8)) || (rc = zp.alloc(size * 8))) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<true>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_mbv, nbits, tc.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(tc.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  u64 zeros = 0;
+  PSG_HIP(hipMemcpyAsync(&zeros, tot.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if ((i64)zeros != size) { set_error("psg_mbv_to_gap: " + std::to_string(zeros) + " zero bits, expected " + std::to_string(size)); return PSG_ECHECK; }
+  hipLaunchKernelGGL(zpos_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_mbv, nbits, tc.as<u64>(), zp.as<u64>());
+  hipLaunchKernelGGL(zpos_to_gap_kernel, dim3((unsigned)cdiv(size + 1, PSG_WG)), dim3(PSG_WG), 0, stream(), zp.as<u64>(), size, nbits, d_gap_out);
+  PSG_HIP(hipGetLastError());
+  PSG_HIP(hipStreamSynchronize(stream()));
+  return 0;
+}
+
+__device__ __forceinline__ int vbyte_len(u64 x) { int l = 1; while (x > 127) { x >>= 7; ++l; } return l; }
+
+__global__ __launch_bounds__(PSG_WG) void vbyte_len_kernel(const u64 *v, i64 n, u64 *tile_sum) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u64 s = 0;
+  for (int q = 0; q < 8; ++q) if (base + q < n) s += vbyte_len(v[base + q]);
+  u64 tot = block_sum<u64>(s, scratch);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PSG_WG) void vbyte_write_kernel(const u64 *v, i64 n, const u64 *tile_pref, u8 *out, i64 cap) {
+  __shared__ u64 scratch[8];
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u64 s = 0;
+  for (int q = 0; q < 8; ++q) if (base + q < n) s += vbyte_len(v[base + q]);
+  u64 tot;
+  u64 p = tile_pref[blockIdx.x] + block_excl_scan<u64>(s, scratch, tot);
+  for (int q = 0; q < 8; ++q) {
+    if (base + q >= n) break;
+    u64 x = v[base + q];
+    while (x > 127) { if ((i64)p < cap) out[p] = (u8)((x & 0x7f) | 0x80); ++p; x >>= 7; }
+    if ((i64)p < cap) out[p] = (u8)x;
+    ++p;
+  }
+}
+
+extern "C" int psg_vbyte_encode(const uint64_t *d_vals, int64_t count, uint8_t *d_out, int64_t cap, int64_t *nbytes) {
+  PSG_REQUIRE(d_vals && d_out && nbytes && count >= 0, "psg_vbyte_encode");
+  *nbytes = 0;
+  if (count == 0) return 0;
+  i64 ntiles = cdiv(count, TILE_V);
+  DevBuf ts, tot;
+  int rc;
+  if ((rc = ts.alloc(ntiles * 8)) || (rc = tot.alloc(8))) return rc;
+  hipLaunchKernelGGL(vbyte_len_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_vals, count, ts.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  u64 total = 0;
+  PSG_HIP(hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  *nbytes = (i64)total;
+  if ((i64)total > cap) { set_error("psg_vbyte_encode: output capacity too small"); return PSG_EINVAL; }
+  hipLaunchKernelGGL(vbyte_write_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_vals, count, ts.as<u64>(), d_out, cap);
+  PSG_HIP(hipGetLastError());
+  PSG_HIP(hipStreamSynchronize(stream()));
+  return 0;
+}
+
+// =======================================================================================
+// K7: final merge.  M_h = merged order of half-blocks h..H-1.  mbv_h marks, for every
+// slot of M_h, whether it holds an own suffix of half-block h (0) or the next element of
+// M_{h+1} (1).  A tile of 4096 output slots walks down the levels: the elements that
+// survive level h form a contiguous range of M_{h+1}.  This is the closed form of the
+// "leftmost half-block whose gap head is 0" rule of merge.hpp:123-158.
+// =======================================================================================
+struct MergeLevel {
+  const u32 *mbv;   // null on the last level
+  i64 nbits;
+  const u64 *samp;  // ones before every TILE_B-bit group
+  const u32 *lo;
+  const u8 *hi;
+  i64 beg, size;
+};
+
+struct psg_merge_plan {
+  int H = 0;
+  i64 n = 0;
+  std::vector<MergeLevel> levels;
+  MergeLevel *d_levels = nullptr;
+  std::vector<void *> owned;
+};
+
+__global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out) {
+  __shared__ u32 scratch[8];
+  __shared__ u16 cur[2][TILE_B];
+  __shared__ u32 vlo[TILE_B];
+  __shared__ u8 vhi[TILE_B];
+  i64 x0 = out_begin + (i64)blockIdx.x * TILE_B;
+  int len = (int)std::min<i64>(TILE_B, out_begin + count - x0);
+  i64 q0 = x0;
+  int cnt = len, s = 0;
+  bool identity = true;
+  int e0 = threadIdx.x * 16;
+  for (int h = 0; h < H && cnt > 0; ++h) {
+    MergeLevel Lh = lv[h];
+    if (h == H - 1) {
+      for (int i = threadIdx.x; i < cnt; i += PSG_WG) {
+        int slot = identity ? i : cur[s][i];
+        i64 idx = q0 + i;
+        u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
+        vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
+      }
+      break;
+    }
+    i64 nwords = (Lh.nbits + 31) >> 5;
+    // ones before q0 = sample + partial popcount inside the group
+    i64 g = q0 >> 12, gbase = g << 12;
+    u32 part = 0;
+    if (threadIdx.x < 128) {
+      i64 wb = gbase + (i64)threadIdx.x * 32;
+      if (wb < q0) {
+        u32 w = lv[h].mbv[wb >> 5];
+        i64 nb = q0 - wb;
+        if (nb < 32) w &= (1u << nb) - 1u;
+        part = __popc(w);
+      }
+    }
+    u32 part_tot = block_sum<u32>(part, scratch);
+    i64 ones_q0 = (i64)Lh.samp[g] + part_tot;
+    i64 zeros_q0 = q0 - ones_q0;
+    int n = std::max(0, std::min(16, cnt - e0));
+    u32 bits = n > 0 ? get_bits(Lh.mbv, q0 + e0, n, nwords) : 0;
+    u32 tot1;
+    u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
+    int z = e0 - (int)o;
+    for (int q = 0; q < n; ++q) {
+      int slot = identity ? e0 + q : cur[s][e0 + q];
+      int below = __popc(bits & ((1u << q) - 1u));
+      if ((bits >> q) & 1u) cur[s ^ 1][o + below] = (u16)slot;
+      else {
+        i64 idx = zeros_q0 + z + q - below;
+        u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
+        vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
+      }
+    }
+    __syncthreads();
+    q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
+  }
+  __syncthreads();
+  // pack 40-bit little-endian (types/uint40.hpp:42-104)
+  u8 *o8 = out + 5 * (x0 - out_begin);
+  int nbytes = 5 * len, nd = nbytes >> 2;
+  for (int d = threadIdx.x; d < nd; d += PSG_WG) {
+    u32 w = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int bb = 4 * d + r, e = bb / 5, rr = bb - 5 * e;
+      u32 byte = rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e];
+      w |= byte << (8 * r);
+    }
+    *(u32 *)(o8 + 4 * d) = w;
+  }
+  for (int bb = nd * 4 + threadIdx.x; bb < nbytes; bb += PSG_WG) {
+    int e = bb / 5, rr = bb - 5 * e;
+    o8[bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
+  }
+}
+
+extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
+  if (!p) return;
+  for (void *q : p->owned) (void)hipFree(q);
+  if (p->d_levels) (void)hipFree(p->d_levels);
+  delete p;
+}
+
+extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out) {
+  PSG_REQUIRE(hbs && H >= 1 && out, "psg_merge_plan_create");
+  psg_merge_plan *p = new psg_merge_plan();
+  p->H = H;
+  std::vector<i64> nh(H + 1, 0);
+  for (int h = H - 1; h >= 0; --h) {
+    if (hbs[h].size < 1 || !hbs[h].d_psa_lo || (h + 1 < H && !hbs[h].d_mbv) || (h > 0 && hbs[h].beg < hbs[h - 1].beg)) {
+      psg_merge_plan_free(p); set_error("psg_merge_plan_create: bad half-block descriptor " + std::to_string(h)); return PSG_EINVAL;
+    }
+    nh[h] = nh[h + 1] + hbs[h].size;
+  }
+  p->n = nh[0];
+  int rc = 0;
+  for (int h = 0; h < H; ++h) {
+    MergeLevel L{};
+    L.lo = hbs[h].d_psa_lo; L.hi = hbs[h].d_psa_hi; L.beg = hbs[h].beg; L.size = hbs[h].size;
+    if (h + 1 < H) {
+      L.mbv = hbs[h].d_mbv; L.nbits = nh[h];
+      i64 ntiles = cdiv(L.nbits, TILE_B);
+      void *samp = nullptr; DevBuf tot;
+      hipError_t e = hipMalloc(&samp, (size_t)(ntiles + 1) * 8);
+      if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
+      p->owned.push_back(samp);
+      if ((rc = tot.alloc(8))) { psg_merge_plan_free(p); return rc; }
+      hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), L.mbv, L.nbits, (u64 *)samp);
+      if ((rc = scan_u64_inplace((u64 *)samp, ntiles, tot.as<u64>()))) { psg_merge_plan_free(p); return rc; }
+      u64 ones = 0;
+      hipError_t e2 = hipMemcpyAsync(&ones, tot.p, 8, hipMemcpyDeviceToHost, stream());
+      hipError_t e3 = hipStreamSynchronize(stream());
+      if (e2 != hipSuccess || e3 != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: device error"); return PSG_EDEVICE; }
+      if ((i64)ones != nh[h + 1]) {
+        psg_merge_plan_free(p);
+        set_error("merge plan: level " + std::to_string(h) + " has " + std::to_string(ones) + " ones, expected " + std::to_string(nh[h + 1]));
+        return PSG_ECHECK;
+      }
+      L.samp = (const u64 *)samp;
+    }
+    p->levels.push_back(L);
+  }
+  hipError_t e = hipMalloc((void **)&p->d_levels, sizeof(MergeLevel) * (size_t)H);
+  if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
+  e = hipMemcpyAsync(p->d_levels, p->levels.data(), sizeof(MergeLevel) * (size_t)H, hipMemcpyHostToDevice, stream());
+  hipError_t e3 = hipStreamSynchronize(stream());
+  if (e != hipSuccess || e3 != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: upload failed"); return PSG_EDEVICE; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64_t out_count, uint8_t *d_out) {
+  PSG_REQUIRE(p && d_out && out_begin >= 0 && out_count >= 0 && out_begin + out_count <= p->n, "psg_merge_run: range");
+  PSG_REQUIRE(((uintptr_t)d_out & 3) == 0, "psg_merge_run: output must be 4-byte aligned");
+  if (out_count == 0) return 0;
+  EventTimer tm; tm.start();
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)cdiv(out_count, TILE_B)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  note_kernel_ms(tm.ms());
+  return 0;
+}

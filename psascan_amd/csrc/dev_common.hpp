@@ -1,0 +1,120 @@
+// dev_common.hpp -- shared host/device helpers of the HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/psascan_amd.h"
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+namespace psg {
+
+// ---- error plumbing ------------------------------------------------------------------
+void set_error(const std::string &s);
+hipStream_t stream();
+void note_kernel_ms(double ms);
+
+#define PSG_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      psg::set_error(std::string(#call) + ": " + hipGetErrorString(e_));                     \
+      return e_ == hipErrorOutOfMemory ? PSG_ENOMEM : PSG_EDEVICE;                           \
+    }                                                                                        \
+  } while (0)
+
+#define PSG_REQUIRE(cond, msg)                                                               \
+  do {                                                                                       \
+    if (!(cond)) { psg::set_error(std::string("invalid argument: ") + msg); return PSG_EINVAL; } \
+  } while (0)
+
+// RAII device buffer for temporaries
+struct DevBuf {
+  void *p = nullptr;
+  i64 bytes = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(i64 b) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = b < 16 ? 16 : b;
+    hipError_t e = hipMalloc(&p, (size_t)bytes);
+    if (e != hipSuccess) { p = nullptr; psg::set_error(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e)); return PSG_ENOMEM; }
+    return 0;
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct EventTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  EventTimer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+  ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  void start() { (void)hipEventRecord(a, stream()); }
+  void stop() { (void)hipEventRecord(b, stream()); }
+  double ms() { float f = 0; (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&f, a, b); return f; }
+};
+
+static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
+
+// single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
+int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);
+
+}  // namespace psg
+
+// ---- device helpers ----------------------------------------------------------------
+#define PSG_WG 256
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
+
+// inclusive scan across the 64 lanes of a wave
+template <class T> __device__ __forceinline__ T wave_incl_scan(T v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if ((int)lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan over a 256-thread workgroup; `total` gets the workgroup sum.
+// scratch: 8 elements of T in LDS.  Contains two barriers.
+template <class T> __device__ __forceinline__ T block_excl_scan(T v, T *scratch, T &total) {
+  T inc = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < PSG_WG / 64; ++k) {
+    T s = scratch[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+
+template <class T> __device__ __forceinline__ T block_sum(T v, T *scratch) {
+  T tot;
+  (void)block_excl_scan(v, scratch, tot);
+  return tot;
+}
+
+// bits [pos, pos+cnt) (cnt <= 32) of an LSB-first u32 bit array; reads at most words
+// pos/32 and pos/32+1 (the second only if needed and < nwords).
+__device__ __forceinline__ u32 get_bits(const u32 *bv, i64 pos, int cnt, i64 nwords) {
+  i64 w = pos >> 5;
+  int sh = (int)(pos & 31);
+  u64 lo = bv[w];
+  u64 hi = (sh + cnt > 32 && w + 1 < nwords) ? bv[w + 1] : 0;
+  u64 x = (lo | (hi << 32)) >> sh;
+  return cnt >= 32 ? (u32)x : (u32)x & ((1u << cnt) - 1u);
+}

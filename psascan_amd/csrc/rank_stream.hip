@@ -1,0 +1,604 @@
+// rank_stream.hip -- K1 (rank structure build) and K2 (streaming gap kernel) for gfx950.
+//
+// Rank layout ("interleaved blocks", HBM-resident): the BWT is cut into blocks of B data
+// bytes; each block is stored as  [CNT x u32 counters][B data bytes]  (STRIDE = 4*CNT+B).
+// counter[code] = #occurrences of that symbol before the block, relative to the enclosing
+// superblock (2^SB_SHIFT blocks); the superblock bases (u64) are folded with the C array of
+// the pass into one LDS table, so a query is: 1 LDS read + 1 counter sector + 1 data sector.
+//   sigma_eff <= 4  : CNT=4,  B=48  -> one 64-byte sector per query
+//   sigma_eff <= 16 : CNT=16, B=64  -> one 128-byte line per query
+//   otherwise       : CNT=256,B=64/128/256 (identity code)
+// Semantics restated from rank4n<>::rank (reference include/rank.hpp:566-568): only the
+// semantics -- the reference's 16 MiB/1 MiB cache-oriented trunks are not reproduced.
+#include "dev_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+using namespace psg;
+
+#define SB_SHIFT 24                 // blocks per superblock = 2^24
+#define SEG_BLOCKS 64               // blocks per build segment (one workgroup)
+#define GROUP_SEGS 256              // segments per scan group
+#define CODE_SHIFT 56
+#define VAL_MASK ((1ull << CODE_SHIFT) - 1ull)
+
+struct psg_rank {
+  i64 m = 0;
+  int cnt = 0, B = 0, stride = 0;
+  i64 nblk = 0, nseg = 0;
+  int nsb = 0;
+  u8 *d_blocks = nullptr;
+  i64 blocks_bytes = 0;
+  u64 *d_sb = nullptr;            // [nsb][cnt]
+  std::vector<u64> h_sb;          // host copy
+  u8 code[256];                   // symbol -> code (0xFF = absent)
+  i64 count[256];                 // occurrences per symbol (m_count, rank.hpp:112)
+};
+
+// ---------------------------------------------------------------------------------------
+// device: count bytes equal to c among the first `off` bytes of a B-byte data area
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 swar_eq_mask(u32 w, u32 c4) {
+  u32 x = w ^ c4;
+  u32 t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
+  return ~t;  // 0x80 in every byte of w equal to c
+}
+
+template <int B> __device__ __forceinline__ u32 count_prefix(const u8 *data, u32 c, int off) {
+  const uint4 *p = (const uint4 *)data;
+  u32 c4 = c * 0x01010101u;
+  u32 acc = 0;
+#pragma unroll
+  for (int q = 0; q < B / 16; ++q) {
+    uint4 v = p[q];
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int rem = off - (q * 16 + k * 4);  // valid bytes in this word (may be <=0 or >=4)
+      u32 keep = rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u >> (32 - 8 * rem)));
+      acc += __popc(swar_eq_mask(w[k], c4) & keep);
+    }
+  }
+  return acc;
+}
+
+template <int CNT, int B> struct RankView {
+  const u8 *blocks;
+  i64 m;
+  static constexpr int STRIDE = 4 * CNT + B;
+};
+
+// One LF step: returns C[c] + rank(i, c) (before the delta / gt corrections).
+// T1: LDS table [nsb][256] of  (C[c] + superblock base) | code << 56 ; tot: LDS [256].
+template <int CNT, int B>
+__device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c) {
+  u64 e0 = T1[c];
+  u32 code = (u32)(e0 >> CODE_SHIFT);
+  i64 Cc = (i64)(e0 & VAL_MASK);
+  if (i <= 0) return Cc;
+  if (i >= R.m) return Cc + (i64)tot[c];
+  if (CNT < 256 && code == 0xFFu) return Cc;
+  i64 blk = i / B;
+  int off = (int)(i - blk * B);
+  const u8 *p = R.blocks + blk * (i64)RankView<CNT, B>::STRIDE;
+  u32 ctr = *(const u32 *)(p + 4 * code);
+  u32 hit = count_prefix<B>(p + 4 * CNT, c, off);
+  i64 sb = blk >> SB_SHIFT;
+  i64 base = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
+  return base + ctr + hit;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 kernels
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PSG_WG) void hist256_kernel(const u8 *bwt, i64 m, unsigned long long *out) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (i64 k = ((i64)blockIdx.x * PSG_WG + threadIdx.x) * 16; k < m; k += (i64)gridDim.x * PSG_WG * 16) {
+    if (k + 16 <= m) {
+      uint4 v = *(const uint4 *)(bwt + k);
+      u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) atomicAdd(&h[(w[q] >> (8 * b)) & 255], 1u);
+    } else {
+      for (i64 j = k; j < m; ++j) atomicAdd(&h[bwt[j]], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+template <int CNT, int B>
+__global__ __launch_bounds__(PSG_WG) void seg_hist_kernel(const u8 *bwt, i64 m, const u8 *code_g, u32 *seg_cnt) {
+  constexpr int SEGSYM = SEG_BLOCKS * B;
+  __shared__ u32 h[CNT];
+  __shared__ u8 code[256];
+  code[threadIdx.x] = code_g[threadIdx.x];
+  for (int k = threadIdx.x; k < CNT; k += PSG_WG) h[k] = 0;
+  __syncthreads();
+  i64 base = (i64)blockIdx.x * SEGSYM;
+  for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) {
+    i64 p = base + k;
+    if (p < m) {
+      u32 cd = code[bwt[p]];
+      if (cd != 0xFFu) atomicAdd(&h[cd], 1u);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < CNT; k += PSG_WG) seg_cnt[(i64)blockIdx.x * CNT + k] = h[k];
+}
+
+// thread per (group, col): serial exclusive prefix over the group's segments (in place)
+__global__ __launch_bounds__(PSG_WG) void group_prefix_kernel(u32 *seg_cnt, i64 nseg, int cnt, u64 *group_sum, i64 ngroups) {
+  i64 t = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (t >= ngroups * cnt) return;
+  i64 g = t / cnt;
+  int col = (int)(t - g * cnt);
+  i64 r0 = g * GROUP_SEGS, r1 = std::min<i64>(r0 + GROUP_SEGS, nseg);
+  u64 run = 0;
+  for (i64 r = r0; r < r1; ++r) {
+    u32 v = seg_cnt[r * cnt + col];
+    seg_cnt[r * cnt + col] = (u32)run;
+    run += v;
+  }
+  group_sum[g * cnt + col] = run;
+}
+
+// one workgroup; thread per col: serial exclusive scan over groups (in place)
+__global__ __launch_bounds__(PSG_WG) void group_scan_kernel(u64 *group_sum, i64 ngroups, int cnt) {
+  int col = threadIdx.x;
+  if (col >= cnt) return;
+  u64 run = 0;
+  for (i64 g = 0; g < ngroups; ++g) {
+    u64 v = group_sum[g * cnt + col];
+    group_sum[g * cnt + col] = run;
+    run += v;
+  }
+}
+
+template <int CNT, int B>
+__global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m, const u8 *code_g, const u32 *seg_pref,
+                                                             const u64 *group_base, u8 *blocks, i64 nblk) {
+  constexpr int SEGSYM = SEG_BLOCKS * B;
+  constexpr int STRIDE = 4 * CNT + B;
+  __shared__ __attribute__((aligned(16))) u8 sym[SEGSYM];
+  __shared__ u16 cnt16[SEG_BLOCKS * CNT];
+  __shared__ u8 code2sym[CNT];
+  i64 seg = blockIdx.x;
+  i64 base = seg * SEGSYM;
+  {
+    u32 cd = code_g[threadIdx.x];
+    if (cd != 0xFFu && cd < CNT) code2sym[cd] = (u8)threadIdx.x;
+  }
+  for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) sym[k] = base + k < m ? bwt[base + k] : 0;
+  __syncthreads();
+  // step 1: per (block, code) counts
+  for (int q = threadIdx.x; q < SEG_BLOCKS * CNT; q += PSG_WG) {
+    int blk = q / CNT, cd = q % CNT;
+    i64 valid = m - (base + (i64)blk * B);
+    int off = valid >= B ? B : (valid <= 0 ? 0 : (int)valid);
+    cnt16[q] = (u16)count_prefix<B>(sym + blk * B, code2sym[cd], off);
+  }
+  __syncthreads();
+  // step 2: exclusive prefix over the 64 blocks, per code
+  for (int cd = threadIdx.x; cd < CNT; cd += PSG_WG) {
+    u32 run = 0;
+    for (int blk = 0; blk < SEG_BLOCKS; ++blk) {
+      u32 v = cnt16[blk * CNT + cd];
+      cnt16[blk * CNT + cd] = (u16)run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  // step 3: counters relative to the superblock base
+  i64 g = seg / GROUP_SEGS;
+  i64 sb = (seg * SEG_BLOCKS) >> SB_SHIFT;
+  i64 sb_group = (sb << SB_SHIFT) / SEG_BLOCKS / GROUP_SEGS;  // group index where the superblock starts
+  for (int q = threadIdx.x; q < SEG_BLOCKS * CNT; q += PSG_WG) {
+    int blk = q / CNT, cd = q % CNT;
+    i64 gb = seg * SEG_BLOCKS + blk;
+    if (gb >= nblk) continue;
+    u64 abs0 = group_base[g * CNT + cd] + seg_pref[seg * CNT + cd];
+    u64 sbb = group_base[sb_group * CNT + cd];
+    *(u32 *)(blocks + gb * STRIDE + 4 * cd) = (u32)(abs0 - sbb) + cnt16[q];
+  }
+  // step 4: data bytes
+  for (int k = threadIdx.x; k < SEGSYM / 4; k += PSG_WG) {
+    int blk = (k * 4) / B, o = (k * 4) % B;
+    i64 gb = seg * SEG_BLOCKS + blk;
+    if (gb >= nblk) continue;
+    *(u32 *)(blocks + gb * STRIDE + 4 * CNT + o) = *(const u32 *)(sym + k * 4);
+  }
+}
+
+// LDS table loader shared by the query / warm-up / stream kernels
+__device__ __forceinline__ void load_tables(u64 *lds, const u64 *g_T1, const u64 *g_tot, int nsb) {
+  for (int k = threadIdx.x; k < nsb * 256; k += blockDim.x) lds[k] = g_T1[k];
+  for (int k = threadIdx.x; k < 256; k += blockDim.x) lds[nsb * 256 + k] = g_tot[k];
+  __syncthreads();
+}
+
+template <int CNT, int B>
+__global__ __launch_bounds__(PSG_WG) void rank_query_kernel(RankView<CNT, B> R, const u64 *g_T1, const u64 *g_tot, int nsb,
+                                                              const i64 *qi, const u8 *qc, i64 nq, i64 *out) {
+  extern __shared__ u64 lds[];
+  load_tables(lds, g_T1, g_tot, nsb);
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k >= nq) return;
+  out[k] = lf_core<CNT, B>(R, lds, lds + nsb * 256, qi[k], qc[k]);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: stream kernel.  One backward-search chain per lane.
+//   chain k covers steps u in [k*L, min((k+1)*L, T));  step u handles text position
+//   j = te - u: consumes symbol tail[T-1-u], gt_in bit u, emits gt_out bit u.
+// ---------------------------------------------------------------------------------------
+struct StreamParams {
+  const u8 *tail;
+  i64 T;
+  const u32 *gt_in;
+  u32 *gt_out;
+  u32 *gap;
+  i64 i0;
+  u32 last;
+  i64 L;
+  i64 nchains;        // entries in this launch
+  const i64 *list;    // chain ids (null = identity)
+  const i64 *init;    // [K] start rank of chain k
+  i64 *fin;           // [K] rank after the chain's last step
+  const u64 *g_T1;
+  const u64 *g_tot;
+  int nsb;
+  int *ovf_flag;
+};
+
+__device__ __forceinline__ u32 byte_of(const uint4 &v, int bi) {
+  u32 w = (bi & 8) ? ((bi & 4) ? v.w : v.z) : ((bi & 4) ? v.y : v.x);
+  return (w >> ((bi & 3) * 8)) & 255u;
+}
+
+template <int CNT, int B, bool CHECK_OVF>
+__global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
+  extern __shared__ u64 lds[];
+  load_tables(lds, P.g_T1, P.g_tot, P.nsb);
+  const u64 *T1 = lds, *tot = lds + P.nsb * 256;
+  i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (gid >= P.nchains) return;
+  i64 k = P.list ? P.list[gid] : gid;
+  i64 u0 = k * P.L;
+  i64 u1 = std::min<i64>(u0 + P.L, P.T);
+  i64 i = P.init[k];
+  // text cursor: descending bytes starting at tail[T-1-u0]
+  uintptr_t addr = (uintptr_t)(P.tail + (P.T - 1 - u0));
+  uintptr_t last_addr = (uintptr_t)(P.tail + (P.T - u1));  // address of the last byte this chain needs
+  const uint4 *cp = (const uint4 *)(addr & ~(uintptr_t)15);
+  int bi = (int)(addr & 15);
+  uint4 cur = *cp, nxt = cur;
+  if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
+  i64 w = u0 >> 5;
+  bool ovf = false;
+  for (i64 u = u0; u < u1; u += 32, ++w) {
+    u32 gin = P.gt_in ? P.gt_in[w] : 0u;
+    u32 gout = 0;
+    int steps = (int)std::min<i64>(32, u1 - u);
+    for (int t = 0; t < steps; ++t) {
+      u32 c = byte_of(cur, bi);
+      bool gt_i0 = i > P.i0;
+      gout |= (u32)gt_i0 << t;
+      i64 ni = lf_core<CNT, B>(R, T1, tot, i, c);
+      ni -= (gt_i0 && c == 0) ? 1 : 0;
+      ni += (c == P.last && ((gin >> t) & 1u)) ? 1 : 0;
+      i = ni;
+      if (CHECK_OVF) {
+        u32 old = atomicAdd(&P.gap[i], 1u);
+        ovf |= (old == 0xFFFFFFFFu);
+      } else {
+        atomicAdd(&P.gap[i], 1u);
+      }
+      if (--bi < 0) {
+        bi = 15;
+        cur = nxt;
+        --cp;
+        if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
+      }
+    }
+    if (P.gt_out) P.gt_out[w] = gout;
+  }
+  P.fin[k] = i;
+  if (CHECK_OVF && ovf) *P.ovf_flag = 1;
+}
+
+// Warm-up: find the start rank of chain k by running the recurrence on an interval
+// [lo, hi] (monotone map) for W steps right of the chain start.  If the interval closes
+// (lo == hi) the start rank is exact.  Chains within W steps of the tail end start from
+// the exact rank_at_tail_end.
+struct WarmParams {
+  const u8 *tail;
+  i64 T;
+  const u32 *gt_in;
+  i64 i0;
+  u32 last;
+  i64 L, W;
+  i64 m;
+  i64 rank_at_end;
+  i64 nitems;
+  const i64 *list;   // chain ids to process (null = all chains 0..nitems-1)
+  i64 *lo, *hi;      // [K]
+  const u64 *g_T1;
+  const u64 *g_tot;
+  int nsb;
+};
+
+template <int CNT, int B>
+__global__ __launch_bounds__(PSG_WG) void warmup_kernel(RankView<CNT, B> R, WarmParams P) {
+  extern __shared__ u64 lds[];
+  load_tables(lds, P.g_T1, P.g_tot, P.nsb);
+  const u64 *T1 = lds, *tot = lds + P.nsb * 256;
+  i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (gid >= P.nitems) return;
+  i64 k = P.list ? P.list[gid] : gid;
+  i64 uend = k * P.L;                // the chain starts at step uend; warm-up covers [ubeg, uend)
+  i64 ubeg = uend - P.W;
+  i64 lo, hi;
+  if (ubeg <= 0) { ubeg = 0; lo = hi = P.rank_at_end; } else { lo = 0; hi = P.m; }
+  for (i64 u = ubeg; u < uend; ++u) {
+    u32 c = P.tail[P.T - 1 - u];
+    u32 g = P.gt_in ? (P.gt_in[u >> 5] >> (u & 31)) & 1u : 0u;
+    i64 add = (c == P.last && g) ? 1 : 0;
+    i64 nlo = lf_core<CNT, B>(R, T1, tot, lo, c) - ((lo > P.i0 && c == 0) ? 1 : 0) + add;
+    i64 nhi = lo == hi ? nlo : lf_core<CNT, B>(R, T1, tot, hi, c) - ((hi > P.i0 && c == 0) ? 1 : 0) + add;
+    lo = nlo; hi = nhi;
+  }
+  P.lo[k] = lo;
+  P.hi[k] = hi;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+#define DISPATCH_LAYOUT(r, F, ...)                                                                   \
+  do {                                                                                               \
+    if ((r)->cnt == 4 && (r)->B == 48) { F<4, 48>(__VA_ARGS__); }                                    \
+    else if ((r)->cnt == 16 && (r)->B == 64) { F<16, 64>(__VA_ARGS__); }                             \
+    else if ((r)->cnt == 256 && (r)->B == 64) { F<256, 64>(__VA_ARGS__); }                           \
+    else if ((r)->cnt == 256 && (r)->B == 128) { F<256, 128>(__VA_ARGS__); }                         \
+    else if ((r)->cnt == 256 && (r)->B == 256) { F<256, 256>(__VA_ARGS__); }                         \
+    else { set_error("unsupported rank layout"); return PSG_EINVAL; }                                \
+  } while (0)
+
+template <int CNT, int B>
+static void launch_build(const u8 *d_bwt, i64 m, const u8 *d_code, u32 *seg_cnt, u64 *group_sum, psg_rank *r, i64 ngroups) {
+  hipLaunchKernelGGL((seg_hist_kernel<CNT, B>), dim3((unsigned)r->nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, d_code, seg_cnt);
+  hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * CNT, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt,
+                     r->nseg, CNT, group_sum, ngroups);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum, ngroups, CNT);
+  hipLaunchKernelGGL((rank_fill_kernel<CNT, B>), dim3((unsigned)r->nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, d_code, seg_cnt,
+                     group_sum, r->d_blocks, r->nblk);
+}
+
+extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, psg_rank_t **out) {
+  PSG_REQUIRE(out && m >= 1 && d_bwt, "psg_rank_build: m >= 1 and non-null pointers required");
+  PSG_REQUIRE(stream() != nullptr, "psg_init() not called");
+  EventTimer tm;
+  tm.start();
+  // phase 0: global histogram -> alphabet -> layout
+  DevBuf hist;
+  if (int rc = hist.alloc(256 * 8)) return rc;
+  PSG_HIP(hipMemsetAsync(hist.p, 0, 256 * 8, stream()));
+  {
+    unsigned grid = (unsigned)std::min<i64>(cdiv(m, (i64)PSG_WG * 16), 2048);
+    hipLaunchKernelGGL(hist256_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), d_bwt, m, hist.as<unsigned long long>());
+    PSG_HIP(hipGetLastError());
+  }
+  u64 h[256];
+  PSG_HIP(hipMemcpyAsync(h, hist.p, sizeof h, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  psg_rank *r = new psg_rank();
+  r->m = m;
+  int sigma = 0;
+  for (int c = 0; c < 256; ++c) { r->count[c] = (i64)h[c]; sigma += h[c] != 0; }
+  if (data_bytes == 0) {
+    if (sigma <= 4) { r->cnt = 4; r->B = 48; }
+    else if (sigma <= 16) { r->cnt = 16; r->B = 64; }
+    else { r->cnt = 256; r->B = 64; }
+  } else if (data_bytes == 48 && sigma <= 4) { r->cnt = 4; r->B = 48; }
+  else if (data_bytes == 64 && sigma <= 16) { r->cnt = 16; r->B = 64; }
+  else if (data_bytes == 64 || data_bytes == 128 || data_bytes == 256) { r->cnt = 256; r->B = data_bytes; }
+  else if (data_bytes == -64) { r->cnt = 256; r->B = 64; }   // force the general layout (tests)
+  else { delete r; set_error("psg_rank_build: data_bytes_per_block must be 0, 48, 64, 128, 256"); return PSG_EINVAL; }
+  if (r->cnt == 256) for (int c = 0; c < 256; ++c) r->code[c] = (u8)c;
+  else { int k = 0; for (int c = 0; c < 256; ++c) r->code[c] = h[c] ? (u8)k++ : 0xFF; }
+  r->stride = 4 * r->cnt + r->B;
+  r->nblk = cdiv(m, r->B);
+  r->nseg = cdiv(r->nblk, SEG_BLOCKS);
+  r->nsb = (int)(((r->nblk - 1) >> SB_SHIFT) + 1);
+  i64 ngroups = cdiv(r->nseg, GROUP_SEGS);
+  r->blocks_bytes = r->nblk * (i64)r->stride;
+  int rc = 0;
+  DevBuf code_d, seg_cnt, group_sum;
+  hipError_t e = hipMalloc((void **)&r->d_blocks, (size_t)r->blocks_bytes);
+  if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
+  if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
+  PSG_HIP(hipMemcpyAsync(code_d.p, r->code, 256, hipMemcpyHostToDevice, stream()));
+  DISPATCH_LAYOUT(r, launch_build, d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  PSG_HIP(hipGetLastError());
+  // superblock bases = group bases at the superblock starts
+  r->h_sb.assign((size_t)r->nsb * r->cnt, 0);
+  for (int s = 0; s < r->nsb; ++s) {
+    i64 g = (((i64)s << SB_SHIFT) / SEG_BLOCKS) / GROUP_SEGS;
+    PSG_HIP(hipMemcpyAsync(&r->h_sb[(size_t)s * r->cnt], group_sum.as<u64>() + g * r->cnt, (size_t)r->cnt * 8, hipMemcpyDeviceToHost, stream()));
+  }
+  tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  note_kernel_ms(tm.ms());
+  *out = r;
+  return 0;
+}
+
+extern "C" void psg_rank_free(psg_rank_t *r) {
+  if (!r) return;
+  if (r->d_blocks) (void)hipFree(r->d_blocks);
+  delete r;
+}
+extern "C" int psg_rank_counts(const psg_rank_t *r, int64_t counts[256]) {
+  PSG_REQUIRE(r && counts, "psg_rank_counts");
+  for (int c = 0; c < 256; ++c) counts[c] = r->count[c];
+  return 0;
+}
+extern "C" int64_t psg_rank_device_bytes(const psg_rank_t *r) { return r ? r->blocks_bytes : 0; }
+
+// T1[sb][c] = (Cadd[c] + sb_base[sb][code[c]]) | code << 56 ; tot[c] = count[c]
+static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &tot) {
+  std::vector<u64> h((size_t)r->nsb * 256), t(256);
+  for (int s = 0; s < r->nsb; ++s)
+    for (int c = 0; c < 256; ++c) {
+      u8 cd = r->code[c];
+      u64 base = cd == 0xFF ? 0 : r->h_sb[(size_t)s * r->cnt + cd];
+      h[(size_t)s * 256 + c] = ((u64)(Cadd ? Cadd[c] : 0) + base) | ((u64)cd << CODE_SHIFT);
+    }
+  for (int c = 0; c < 256; ++c) t[c] = (u64)r->count[c];
+  if (int rc = T1.alloc((i64)h.size() * 8)) return rc;
+  if (int rc = tot.alloc(256 * 8)) return rc;
+  PSG_HIP(hipMemcpyAsync(T1.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream()));
+  PSG_HIP(hipMemcpyAsync(tot.p, t.data(), 256 * 8, hipMemcpyHostToDevice, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));  // h, t go out of scope
+  return 0;
+}
+
+template <int CNT, int B>
+static void launch_query(const psg_rank *r, const u64 *T1, const u64 *tot, const i64 *qi, const u8 *qc, i64 nq, i64 *out) {
+  RankView<CNT, B> R{r->d_blocks, r->m};
+  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  hipLaunchKernelGGL((rank_query_kernel<CNT, B>), dim3((unsigned)cdiv(nq, PSG_WG)), dim3(PSG_WG), lds, stream(), R, T1, tot,
+                     r->nsb, qi, qc, nq, out);
+}
+
+extern "C" int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uint8_t *d_c, int64_t nq, int64_t *d_out) {
+  PSG_REQUIRE(r && nq >= 0, "psg_rank_query");
+  if (nq == 0) return 0;
+  DevBuf T1, tot;
+  if (int rc = make_tables(r, nullptr, T1, tot)) return rc;
+  DISPATCH_LAYOUT(r, launch_query, r, T1.as<u64>(), tot.as<u64>(), d_i, d_c, nq, d_out);
+  PSG_HIP(hipGetLastError());
+  PSG_HIP(hipStreamSynchronize(stream()));
+  return 0;
+}
+
+template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams P) {
+  RankView<CNT, B> R{r->d_blocks, r->m};
+  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
+}
+template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, bool check_ovf) {
+  RankView<CNT, B> R{r->d_blocks, r->m};
+  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  dim3 grid((unsigned)cdiv(P.nchains, PSG_WG));
+  if (check_ovf) hipLaunchKernelGGL((stream_kernel<CNT, B, true>), grid, dim3(PSG_WG), lds, stream(), R, P);
+  else hipLaunchKernelGGL((stream_kernel<CNT, B, false>), grid, dim3(PSG_WG), lds, stream(), R, P);
+}
+
+extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
+                              const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out,
+                              int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
+  PSG_REQUIRE(r && d_gap, "psg_stream_gap: rank and gap required");
+  PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");
+  PSG_REQUIRE(rank_at_end >= 0 && rank_at_end <= r->m, "psg_stream_gap: rank_at_tail_end out of range");
+  psg_stream_stats st = {};
+  if (T == 0) { if (h_final_rank) *h_final_rank = rank_at_end; if (stats) *stats = st; return 0; }
+  PSG_REQUIRE(d_tail, "psg_stream_gap: tail text required");
+  EventTimer total_tm, ktm;
+  total_tm.start();
+  // C array of the pass: compute_gap.hpp:77-85
+  i64 C[256], s = 0;
+  for (int c = 0; c < 256; ++c) { i64 t = r->count[c] + (c == last_sym) - (c == 0); C[c] = s; s += t; }
+  DevBuf T1, tot;
+  if (int rc = make_tables(r, C, T1, tot)) return rc;
+  // chain plan
+  i64 Ktarget = max_chains > 0 ? max_chains : (i64)256 * 32 * 64;
+  i64 L = cdiv(cdiv(T, Ktarget), 64) * 64;
+  i64 K = cdiv(T, L);
+  st.n_chains = K; st.chain_len = L;
+  DevBuf lo_d, hi_d, fin_d, list_d, flag_d;
+  int rc;
+  if ((rc = lo_d.alloc(K * 8)) || (rc = hi_d.alloc(K * 8)) || (rc = fin_d.alloc(K * 8)) || (rc = list_d.alloc(K * 8)) || (rc = flag_d.alloc(4))) return rc;
+  PSG_HIP(hipMemsetAsync(flag_d.p, 0, 4, stream()));
+  std::vector<i64> lo(K), hi(K), fin(K, -1), list;
+  std::vector<char> resolved(K, 0), done(K, 0);
+  WarmParams WP{d_tail, T, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
+  // warm-up with growing W for the chains that did not resolve
+  i64 nun = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    DISPATCH_LAYOUT(r, launch_warm, r, WP);
+    PSG_HIP(hipGetLastError());
+    PSG_HIP(hipMemcpyAsync(lo.data(), lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(hipMemcpyAsync(hi.data(), hi_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(hipStreamSynchronize(stream()));
+    list.clear();
+    for (i64 k = 0; k < K; ++k) { resolved[k] = lo[k] == hi[k]; if (!resolved[k]) list.push_back(k); }
+    st.warmup_steps = WP.W;
+    nun = (i64)list.size();
+    if (nun == 0) break;
+    WP.W *= 16;
+    WP.nitems = nun;
+    WP.list = list_d.as<i64>();
+    PSG_HIP(hipMemcpyAsync(list_d.p, list.data(), nun * 8, hipMemcpyHostToDevice, stream()));
+    PSG_HIP(hipStreamSynchronize(stream()));
+  }
+  st.unresolved = nun;
+  bool check_ovf = T >= 0xFFFFFFFFll;
+  StreamParams SP{d_tail, T, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>()};
+  double kms = 0;
+  i64 ndone = 0;
+  // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
+  // known once chain k-1 (to its right in the text) has finished: fin[k-1] == init[k].
+  std::vector<i64> ready;
+  while (ndone < K) {
+    ready.clear();
+    for (i64 k = 0; k < K; ++k)
+      if (!done[k] && (resolved[k] || (k > 0 && done[k - 1]))) {
+        if (!resolved[k]) { lo[k] = fin[k - 1]; resolved[k] = 1; }
+        ready.push_back(k);
+      }
+    if (ready.empty()) { set_error("stream: no runnable chain (internal error)"); return PSG_ECHECK; }
+    if (nun > 0) {  // start ranks may have been patched on the host
+      PSG_HIP(hipMemcpyAsync(lo_d.p, lo.data(), K * 8, hipMemcpyHostToDevice, stream()));
+    }
+    if ((i64)ready.size() == K) { SP.list = nullptr; SP.nchains = K; }
+    else {
+      PSG_HIP(hipMemcpyAsync(list_d.p, ready.data(), ready.size() * 8, hipMemcpyHostToDevice, stream()));
+      SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
+    }
+    ktm.start();
+    DISPATCH_LAYOUT(r, launch_stream, r, SP, check_ovf);
+    ktm.stop();
+    PSG_HIP(hipGetLastError());
+    PSG_HIP(hipMemcpyAsync(fin.data(), fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(hipStreamSynchronize(stream()));
+    kms += ktm.ms();
+    for (i64 k : ready) done[k] = 1;
+    ndone += (i64)ready.size();
+    st.rounds++;
+  }
+  // invariant: the rank a chain ends with is the start rank of the next chain
+  for (i64 k = 1; k < K; ++k)
+    if (fin[k - 1] != lo[k]) {
+      set_error("stream: chain hand-over check failed at chain " + std::to_string(k) + " (fin=" + std::to_string(fin[k - 1]) + " init=" + std::to_string(lo[k]) + ")");
+      return PSG_ECHECK;
+    }
+  if (lo[0] != rank_at_end) { set_error("stream: chain 0 did not start at rank_at_tail_end"); return PSG_ECHECK; }
+  int ovf = 0;
+  PSG_HIP(hipMemcpyAsync(&ovf, flag_d.p, 4, hipMemcpyDeviceToHost, stream()));
+  total_tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if (ovf) { set_error("stream: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
+  st.kernel_ms = kms;
+  st.total_ms = total_tm.ms();
+  note_kernel_ms(kms);
+  if (h_final_rank) *h_final_rank = fin[K - 1];
+  if (stats) *stats = st;
+  return 0;
+}

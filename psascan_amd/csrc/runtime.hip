@@ -1,0 +1,178 @@
+// runtime.hip -- device selection, memory helpers, error state, small bit utilities.
+#include "dev_common.hpp"
+
+#include <mutex>
+
+namespace psg {
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static bool g_own_stream = false;
+static bool g_inited = false;
+static double g_last_ms = 0;
+
+void set_error(const std::string &s) { g_err = s; }
+hipStream_t stream() { return g_stream; }
+void note_kernel_ms(double ms) { g_last_ms = ms; }
+
+// ---- single-workgroup scan ------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_u64_kernel(u64 *vals, i64 n, u64 *total) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  int w = threadIdx.x >> 6;
+  for (i64 base = 0; base < n; base += 1024) {
+    i64 k = base + threadIdx.x;
+    u64 v = k < n ? vals[k] : 0;
+    u64 inc = wave_incl_scan(v);
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    u64 pre = carry_s, tot = 0;
+    for (int q = 0; q < 16; ++q) { u64 s = wsum[q]; if (q < w) pre += s; tot += s; }
+    if (k < n) vals[k] = pre + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total) {
+  hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, stream(), d_vals, n, d_total);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- bitcopy ---------------------------------------------------------------------------
+// one thread per destination word that is touched; edge words use atomics with masks.
+__global__ __launch_bounds__(PSG_WG) void bitcopy_kernel(u32 *dst, i64 dst_bit, const u32 *src, i64 src_bit, i64 nbits,
+                                                           i64 src_words) {
+  i64 first_w = dst_bit >> 5, last_w = (dst_bit + nbits - 1) >> 5;
+  i64 w = first_w + (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (w > last_w) return;
+  i64 lo = w << 5;                       // first dst bit of this word
+  i64 b0 = lo < dst_bit ? dst_bit : lo;  // valid range [b0, b1)
+  i64 b1 = lo + 32 < dst_bit + nbits ? lo + 32 : dst_bit + nbits;
+  int cnt = (int)(b1 - b0);
+  u32 v = get_bits(src, src_bit + (b0 - dst_bit), cnt, src_words) << (int)(b0 - lo);
+  if (cnt == 32) { dst[w] = v; return; }
+  u32 mask = (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u)) << (int)(b0 - lo);
+  atomicAnd(&dst[w], ~mask);
+  atomicOr(&dst[w], v);
+}
+
+__global__ __launch_bounds__(PSG_WG) void popcount_kernel(const u32 *bits, i64 nbits, unsigned long long *out) {
+  __shared__ u64 scratch[8];
+  i64 nw = (nbits + 31) >> 5;
+  u64 acc = 0;
+  for (i64 w = (i64)blockIdx.x * PSG_WG + threadIdx.x; w < nw; w += (i64)gridDim.x * PSG_WG) {
+    u32 x = bits[w];
+    if (w == nw - 1 && (nbits & 31)) x &= (1u << (nbits & 31)) - 1u;
+    acc += __popc(x);
+  }
+  u64 tot = block_sum<u64>(acc, scratch);
+  if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long)tot);
+}
+}  // namespace psg
+
+using namespace psg;
+
+extern "C" {
+
+int psg_init(int device) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0) {
+    set_error(std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+              " -- psascan_amd has no CPU fallback");
+    return PSG_EDEVICE;
+  }
+  PSG_REQUIRE(device >= 0 && device < cnt, "device index out of range");
+  PSG_HIP(hipSetDevice(device));
+  if (!g_stream) {
+    PSG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_own_stream = true;
+  }
+  g_inited = true;
+  return 0;
+}
+
+int psg_set_stream(void *s) {
+  if (g_own_stream && g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); }
+  g_own_stream = false;
+  g_stream = (hipStream_t)s;
+  if (!s) {
+    PSG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_own_stream = true;
+  }
+  g_inited = true;
+  return 0;
+}
+
+const char *psg_last_error(void) { return g_err.c_str(); }
+double psg_last_kernel_ms(void) { return g_last_ms; }
+
+int psg_device_name(char *buf, int cap) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  PSG_HIP(hipGetDevice(&dev));
+  PSG_HIP(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return 0;
+}
+
+int psg_malloc(void **d_ptr, int64_t bytes) {
+  PSG_REQUIRE(d_ptr && bytes >= 0, "psg_malloc");
+  hipError_t e = hipMalloc(d_ptr, (size_t)(bytes < 16 ? 16 : bytes));
+  if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); *d_ptr = nullptr; return e == hipErrorOutOfMemory ? PSG_ENOMEM : PSG_EDEVICE; }
+  return 0;
+}
+int psg_free(void *d_ptr) { if (d_ptr) PSG_HIP(hipFree(d_ptr)); return 0; }
+int psg_memset(void *d_ptr, int value, int64_t bytes) {
+  if (bytes > 0) PSG_HIP(hipMemsetAsync(d_ptr, value, (size_t)bytes, stream()));
+  return 0;
+}
+int psg_h2d(void *d, const void *h, int64_t bytes) {
+  if (bytes > 0) { PSG_HIP(hipMemcpyAsync(d, h, (size_t)bytes, hipMemcpyHostToDevice, stream())); PSG_HIP(hipStreamSynchronize(stream())); }
+  return 0;
+}
+int psg_d2h(void *h, const void *d, int64_t bytes) {
+  if (bytes > 0) { PSG_HIP(hipMemcpyAsync(h, d, (size_t)bytes, hipMemcpyDeviceToHost, stream())); PSG_HIP(hipStreamSynchronize(stream())); }
+  return 0;
+}
+int psg_d2d(void *dd, const void *ds, int64_t bytes) {
+  if (bytes > 0) PSG_HIP(hipMemcpyAsync(dd, ds, (size_t)bytes, hipMemcpyDeviceToDevice, stream()));
+  return 0;
+}
+int psg_sync(void) { PSG_HIP(hipStreamSynchronize(stream())); return 0; }
+
+int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t src_bit, int64_t nbits) {
+  PSG_REQUIRE(dst_bit >= 0 && src_bit >= 0 && nbits >= 0, "psg_bitcopy");
+  if (nbits == 0) return 0;
+  i64 nwords = ((dst_bit + nbits - 1) >> 5) - (dst_bit >> 5) + 1;
+  i64 src_words = (src_bit + nbits + 31) >> 5;
+  hipLaunchKernelGGL(bitcopy_kernel, dim3((unsigned)cdiv(nwords, PSG_WG)), dim3(PSG_WG), 0, stream(), d_dst, dst_bit, d_src,
+                     src_bit, nbits, src_words);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
+int psg_popcount(const uint32_t *d_bits, int64_t nbits, int64_t *ones) {
+  PSG_REQUIRE(nbits >= 0 && ones, "psg_popcount");
+  DevBuf acc;
+  if (int rc = acc.alloc(8)) return rc;
+  PSG_HIP(hipMemsetAsync(acc.p, 0, 8, stream()));
+  if (nbits > 0) {
+    i64 nw = (nbits + 31) >> 5;
+    unsigned grid = (unsigned)std::min<i64>(cdiv(nw, PSG_WG), 4096);
+    hipLaunchKernelGGL(popcount_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), d_bits, nbits, acc.as<unsigned long long>());
+    PSG_HIP(hipGetLastError());
+  }
+  u64 v = 0;
+  PSG_HIP(hipMemcpyAsync(&v, acc.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  *ones = (i64)v;
+  return 0;
+}
+
+}  // extern "C"

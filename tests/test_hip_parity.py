@@ -1,0 +1,264 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Bit-exact: everything
+on this path is integer / byte / index work.  Needs a real MI355X: `pytest -m gpu`."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from golden import inputs as gin
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def A(gpu_lib):
+    import psascan_amd.api as api
+    return api
+
+
+def make_text(kind, n, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "rand255":
+        return rng.integers(0, 255, n, dtype=np.uint8)
+    if kind == "sig4z":
+        return rng.integers(0, 4, n, dtype=np.uint8)
+    if kind == "dna":
+        return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]
+    if kind == "sig12":
+        return rng.integers(40, 52, n, dtype=np.uint8)
+    if kind == "alla":
+        return np.full(n, 97, np.uint8)
+    if kind == "fib":
+        return gin.fib()[:n].copy()
+    if kind == "per3":
+        return np.frombuffer((b"abc" * (n // 3 + 1))[:n], np.uint8).copy()
+    if kind == "zeros":
+        return np.zeros(n, np.uint8)
+    raise KeyError(kind)
+
+
+KINDS = ["rand255", "sig4z", "dna", "sig12", "alla", "fib", "per3", "zeros"]
+
+
+# ------------------------------------------------------------------ rank (a3)
+@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 128), (255, 256), (4, 0), (4, -64), (12, 0), (2, 0), (1, 0)])
+@pytest.mark.parametrize("m", [1, 47, 48, 49, 64, 4095, 4096, 4097, 100003])
+def test_rank_query(A, sigma, layout, m):
+    rng = np.random.default_rng(m * 7 + sigma)
+    bwt = rng.integers(0, sigma, m, dtype=np.uint8)
+    if sigma == 12:
+        bwt = bwt * 20 + 3
+    r = A.rank_build(A.upload(bwt, pad_to=16), m, layout)
+    rk = orc.Rank(bwt)
+    assert np.array_equal(r.counts, rk.counts())
+    qi = np.concatenate([rng.integers(-3, m + 4, 3000), np.arange(-1, min(m, 200) + 2), [m - 1, m, m + 1]]).astype(np.int64)
+    qc = rng.integers(0, 256, len(qi)).astype(np.uint8)
+    qc[::2] = bwt[rng.integers(0, m, len(qc[::2]))]
+    got = r.query(qi, qc)
+    want = np.array([rk.rank(i, c) for i, c in zip(qi, qc)], np.int64)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ one streaming pass (a1,a2,a4)
+def _stream_case(t, b, e, tb, te):
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    psa, bwt, i0, _ = orc.partial_sa(t, sa, isa, b, e)
+    gt_in = orc.packbits([(isa[te - u] if te - u < n else -1) > isa[e] for u in range(te - tb)])
+    init = int((isa[b:e] < (isa[te] if te < n else -1)).sum())
+    return bwt, i0, gt_in, init
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("chains", [0, 1, 7])
+def test_stream_gap_vs_oracle(A, kind, chains):
+    n = 9000
+    t = make_text(kind, n, 3)
+    b, e = n // 9, n // 9 + n // 4
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m = e - b
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text = A.upload(t, pad_to=16)
+    T = n - e
+    d_gap = A.zeros(4 * (m + 2))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, chains)
+    assert fin == want_fin
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+    if chains == 7:
+        assert st.n_chains > 1
+
+
+def test_stream_gap_mid_tail_and_accumulate(A):
+    """tail range that does not end at n (pass A shape) + accumulation into a non-zero gap array."""
+    n = 20000
+    t = make_text("sig4z", n, 5)
+    b, mid, e = 1000, 6000, 11000
+    bwt, i0, gt_in, init = _stream_case(t, b, mid, mid, e)
+    m = mid - b
+    T = e - mid
+    rk = orc.Rank(bwt)
+    want_gap, want_gt, want_fin = orc.stream_pass(rk, i0, t[mid - 1], t, mid, e, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text = A.upload(t, pad_to=16)
+    d_gap = A.upload(np.full(m + 1, 5, np.uint32))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    fin, st = A.stream_gap(r, i0, t[mid - 1], d_text.at(mid), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, 64)
+    assert fin == want_fin and st.n_chains > 8
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap + 5)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
+def test_stream_gap_empty_tail(A):
+    bwt = np.array([0, 1, 2, 1], np.uint8)
+    r = A.rank_build(A.upload(bwt, pad_to=16), 4)
+    d_gap = A.zeros(32)
+    fin, _ = A.stream_gap(r, 0, 1, None, 0, None, 3, d_gap, None)
+    assert fin == 3
+    assert not A.download(d_gap, np.uint32, 5).any()
+
+
+# ------------------------------------------------------------------ bitvector / BWT merge / split (a5-a9)
+@pytest.mark.parametrize("kind", KINDS)
+def test_block_steps_vs_oracle(A, kind):
+    n = 30000
+    t = make_text(kind, n, 11)
+    b, e = n // 7, n // 7 + n // 2 + 1
+    mid = b + (e - b) // 2
+    ml, mr, bs, T = mid - b, e - mid, e - b, n - e
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    lpsa, lbwt, li0, _ = orc.partial_sa(t, sa, isa, b, mid)
+    rpsa, rbwt, ri0, rgt = orc.partial_sa(t, sa, isa, mid, e)
+    initA = int((isa[b:mid] < isa[e]).sum())
+    gapA, gtA, _ = orc.stream_pass(orc.Rank(lbwt), li0, t[mid - 1], t, mid, e, rgt, initA)
+    bv, nb = orc.gap_to_bitvector(gapA, ml)
+    bbwt, bi0 = orc.merge_bwt(lbwt, rbwt, li0, ri0, t[mid - 1], bv)
+    gt_in = orc.packbits([(isa[n - u] if n - u < n else -1) > isa[e] for u in range(T)])
+    gapB, _, _ = orc.stream_pass(orc.Rank(bbwt), bi0, t[e - 1], t, e, n, gt_in, 0)
+    rg, lg = orc.right_gap(gapB, bv, ml, mr), orc.left_gap(gapB, bv, ml, mr)
+    # device
+    d_gapA = A.upload(gapA.astype(np.uint32))
+    d_bv = A.zeros(4 * ((bs + 31) // 32 + 2))
+    assert A.gap_to_bitvector(d_gapA, ml, d_bv, bs) == bs
+    assert np.array_equal(orc.bits(A.download(d_bv, np.uint8, (bs + 7) // 8), bs), orc.bits(bv, bs))
+    d_out = A.DeviceBuffer(bs + 16)
+    got_i0 = A.merge_bwt(A.upload(lbwt, 16), A.upload(rbwt, 16), ml, mr, li0, ri0, t[mid - 1], d_bv, d_out)
+    assert got_i0 == bi0
+    assert np.array_equal(A.download(d_out, np.uint8, bs), bbwt)
+    d_gapB = A.upload(gapB.astype(np.uint32))
+    mbvL = A.DeviceBuffer(4 * ((bs + T + 31) // 32 + 1))
+    mbvR = A.DeviceBuffer(4 * ((mr + T + 31) // 32 + 1))
+    A.split_gap(d_gapB, d_bv, ml, mr, T, mbvL, mbvR)
+    got_lg = A.download(A.mbv_to_gap(mbvL, bs + T, ml), np.uint64, ml + 1)
+    got_rg = A.download(A.mbv_to_gap(mbvR, mr + T, mr), np.uint64, mr + 1)
+    assert np.array_equal(got_lg, lg)
+    assert np.array_equal(got_rg, rg)
+    # vbyte of the gap file (a10)
+    d_vals = A.upload(lg)
+    d_vb, nbytes = A.vbyte_encode(d_vals, len(lg))
+    assert np.array_equal(A.download(d_vb, np.uint8, nbytes), orc.vbyte_encode(lg))
+
+
+def test_vbyte_large_values(A):
+    vals = np.array([0, 1, 127, 128, 300, 16383, 16384, 2 ** 32, 2 ** 40 - 1, 2 ** 63] * 300, np.uint64)
+    d_vb, nb = A.vbyte_encode(A.upload(vals), len(vals))
+    assert np.array_equal(A.download(d_vb, np.uint8, nb), orc.vbyte_encode(vals))
+
+
+def test_bitcopy_and_popcount(A):
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, 4000, dtype=np.uint8)
+    for (db, sb, nb) in [(0, 0, 31999), (5, 0, 1000), (0, 7, 1000), (37, 91, 20001), (64, 64, 64), (31, 1, 1), (100, 3, 31)]:
+        dst0 = rng.integers(0, 256, 4100, dtype=np.uint8)
+        d_dst, d_src = A.upload(dst0), A.upload(src)
+        A.bitcopy(d_dst, db, d_src, sb, nb)
+        want = orc.bits(dst0, 4100 * 8).copy()
+        want[db:db + nb] = orc.bits(src, 4000 * 8)[sb:sb + nb]
+        assert np.array_equal(orc.bits(A.download(d_dst, np.uint8, 4100), 4100 * 8), want)
+    assert A.popcount(A.upload(src), 31991) == int(orc.bits(src, 31991).sum())
+
+
+# ------------------------------------------------------------------ final merge (a11, a12)
+@pytest.mark.parametrize("cuts", [[0, 5000], [0, 2500, 5000], [0, 700, 1500, 1501, 2600, 3333, 4100, 5000],
+                                  list(range(0, 5001, 250))])
+def test_merge_vs_oracle(A, cuts):
+    rng = np.random.default_rng(13)
+    t = rng.integers(0, 3, 5000, dtype=np.uint8)
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    hbs, begs, sizes, psas, gaps = [], [], [], [], []
+    for h in range(len(cuts) - 1):
+        b, e = cuts[h], cuts[h + 1]
+        psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+        ranks = np.searchsorted(np.sort(isa[b:e]), isa[e:n])      # r_B(p) for every p >= e
+        g = np.bincount(ranks, minlength=e - b + 1).astype(np.uint64)
+        begs.append(b); sizes.append(e - b); psas.append(psa); gaps.append(g if e < n else None)
+        mbv = None
+        if e < n:
+            bv, nb = orc.gap_to_bitvector(g, e - b)
+            assert nb == n - b
+            mbv = A.upload(bv[: (nb + 7) // 8])
+        hbs.append({"beg": b, "size": e - b, "psa_lo": A.upload(psa.astype(np.uint32)), "psa_hi": None, "mbv": mbv})
+    want = orc.merge(begs, sizes, psas, gaps)
+    d_out = A.merge_half_blocks(hbs)
+    assert np.array_equal(A.download(d_out, np.uint8, 5 * n), want)
+    # ranged output (multi-GPU partitioning of the output)
+    plan = A.MergePlan(hbs)
+    d_part = A.DeviceBuffer(5 * 1234 + 8)
+    plan.run(777, 1234, d_part)
+    assert np.array_equal(A.download(d_part, np.uint8, 5 * 1234), want[5 * 777: 5 * (777 + 1234)])
+
+
+def test_merge_high_byte(A):
+    """half-block offsets beyond 2^32 (psa_hi) and beg beyond 2^32: uint40 packing."""
+    psa0 = np.array([3, 2 ** 32 + 5, 7], np.uint64)
+    psa1 = np.array([1, 0], np.uint64)
+    bv = orc.packbits([0, 1, 0, 1, 0])             # order: a0 b0 a1 b1 a2
+    hbs = [{"beg": 10, "size": 3, "psa_lo": A.upload((psa0 & np.uint64(0xFFFFFFFF)).astype(np.uint32)),
+            "psa_hi": A.upload((psa0 >> np.uint64(32)).astype(np.uint8)), "mbv": A.upload(bv)},
+           {"beg": 2 ** 39, "size": 2, "psa_lo": A.upload(psa1.astype(np.uint32)), "psa_hi": None, "mbv": None}]
+    got = orc.sa5_to_sa(A.download(A.merge_half_blocks(hbs), np.uint8, 25))
+    assert list(got) == [13, 2 ** 39 + 1, 2 ** 32 + 15, 2 ** 39, 17]
+
+
+# ------------------------------------------------------------------ whole path vs the reference's hashes
+def oracle_sorter(sa, isa):
+    def sorter(text, beg, end, gt_tail):
+        psa, bwt, i0, gt = orc.partial_sa(text, sa, isa, beg, end)
+        return {"psa": psa, "bwt": bwt, "i0": i0, "gt_begin": gt}
+    return sorter
+
+
+@pytest.mark.parametrize("name", list(GOLD.keys() - {"_comment"}))
+def test_pipeline_vs_reference_hashes(A, name):
+    from psascan_amd import pipeline
+    g = GOLD[name]
+    t = gin.GENERATORS[name]()
+    sa = orc.suffix_array(t)
+    st = []
+    out = pipeline.construct_sa5(t, g["max_block_size"], g["ram_use"], oracle_sorter(sa, orc.inverse(sa)),
+                                 max_chains=256, stats=st)
+    assert hashlib.sha256(bytes(out)).hexdigest() == g["sa5_sha256"]
+    assert len(st) > 0
+
+
+@pytest.mark.parametrize("n,mb", [(1, 4), (2, 4), (3, 2), (17, 4), (1000, 64), (1000, 999), (1001, 77), (5000, 5000)])
+def test_pipeline_small_shapes(A, n, mb):
+    from psascan_amd import pipeline
+    rng = np.random.default_rng(n * 31 + mb)
+    t = rng.integers(0, 3, n, dtype=np.uint8)
+    sa = orc.suffix_array(t)
+    for ram in (int(mb * 5.2) + 1, 30, 10 * 1000000):
+        out = pipeline.construct_sa5(t, mb, ram, oracle_sorter(sa, orc.inverse(sa)), max_chains=16)
+        assert np.array_equal(orc.sa5_to_sa(out), sa)
