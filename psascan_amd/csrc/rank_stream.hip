@@ -170,7 +170,10 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
   __shared__ u8 code2sym[CNT];
   i64 seg = blockIdx.x;
   i64 base = seg * SEGSYM;
-  {
+  if (CNT == 256) code2sym[threadIdx.x % CNT] = (u8)threadIdx.x;   // identity code
+  else {
+    if (threadIdx.x < CNT) code2sym[threadIdx.x] = 0;             // unused code slots
+    __syncthreads();
     u32 cd = code_g[threadIdx.x];
     if (cd != 0xFFu && cd < CNT) code2sym[cd] = (u8)threadIdx.x;
   }
