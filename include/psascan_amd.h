@@ -92,6 +92,19 @@ int psg_stream_gap(const psg_rank_t *rank, int64_t block_i0, int block_last_symb
                    int64_t rank_at_tail_end, uint32_t *d_gap, uint32_t *d_gt_out,
                    int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats);
 
+/* Same pass over a sub-range of a tail (the reference cuts the tail into per-thread ranges the
+ * same way, compute_gap.hpp:68-69,114-124): `right_context` more text bytes / gt bits are valid
+ * to the right of the range.  d_tail = text[tail_begin .. tail_end + right_context), gt_in bit u
+ * <-> position (tail_end + right_context) - u, and rank_at_context_end is the exact rank at
+ * tail_end + right_context, or -1 if it is not known.  The start rank at tail_end is found on the device inside the context
+ * (PSG_ECHECK if the text is too repetitive for that).  gt_out bit u <-> position tail_end - u.
+ * right_context must be a multiple of 64.                                                    */
+int psg_stream_gap_ctx(const psg_rank_t *rank, int64_t block_i0, int block_last_symbol,
+                       const uint8_t *d_tail, int64_t tail_len, int64_t right_context,
+                       const uint32_t *d_gt_in, int64_t rank_at_context_end, uint32_t *d_gap,
+                       uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank,
+                       psg_stream_stats *stats);
+
 /* ---- buffered_gap_array::convert_to_bitvector, partial_sufsort.hpp:441
  *      (gap_array.hpp:273-364): for j=0..m: gap[j] ones, then a zero (none after j=m).
  *      d_bv needs room for m + sum(gap) bits rounded up to 32; *nbits = m + sum(gap). ---- */

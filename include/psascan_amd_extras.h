@@ -1,0 +1,28 @@
+/*
+ * psascan_amd_extras.h -- synthetic-input preparation (bench / full-size property tests).
+ * NOT part of the drop-in boundary (see psascan_amd.h for that): the reference sorts
+ * half-blocks on the host (inmem_psascan_src/inmem_psascan.hpp:64-304) and construct_sa does
+ * the same.  These helpers exist so that bench.py can build valid multi-GiB hot-path inputs
+ * (text, partial SA, BWT, i0, gt_begin) inside HBM within minutes.
+ */
+#ifndef PSASCAN_AMD_EXTRAS_H
+#define PSASCAN_AMD_EXTRAS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* seeded text: mode 0 = uniform bytes 0..254, 1 = DNA (ACGT), 2 = `sigma` letters from 'a' */
+int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, uint64_t seed);
+/* partial SA (relative to beg), BWT (dummy 0 at i0), i0 and gt_begin (bit u <-> position
+ * end-u, u in [0,size)) of text[beg..end) ordered as suffixes of the whole text.  Prefix-key
+ * radix sort + comparison of equal-key groups: only for texts with short repeats.        */
+int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa,
+                        uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups);
+/* property check of `count` uint40 entries: sum of entries mod 2^64, and the number of sampled
+ * adjacent pairs (k, k+1) that are NOT in suffix order.                                      */
+int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples,
+                   uint64_t seed, int64_t *bad_pairs, uint64_t *sum);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -38,6 +38,10 @@
 
 using namespace psascan_private;
 
+static double g_last_seconds = 0;   // wall time spent inside the reference call proper
+static double g_rank_seconds = 0;
+static double now_s() { return (double)utils::wclock(); }
+
 static void silence(bool on) {
   static int saved = -1;
   if (on) { fflush(stderr); saved = dup(2); FILE *f = fopen("/dev/null", "w"); dup2(fileno(f), 2); fclose(f); }
@@ -58,7 +62,13 @@ static void gap_to_values(buffered_gap_array *g, uint64_t *out) {
   g->stop_sequential_access();
 }
 
+static long g_threads = 2;
+
 extern "C" {
+
+double ref_last_seconds(void) { return g_last_seconds; }
+double ref_last_rank_build_seconds(void) { return g_rank_seconds; }
+void ref_set_threads(long t) { g_threads = t > 0 ? t : 1; }
 
 // rank4n<>::rank (rank.hpp:566-708) and m_count (rank.hpp:112)
 int ref_rank(const uint8_t *bwt, long m, const long *qi, const uint8_t *qc, long nq, long *out, long *counts256) {
@@ -88,11 +98,15 @@ int ref_compute_gap(const uint8_t *bwt, long m, long i0, int last, const uint8_t
     gt_in_mf->add_file(n - te, n - tb, fn);
   }
   multifile *gt_out_mf = new multifile();
-  rank4n<> *r = new rank4n<>(bwt, (unsigned long)m, 2);
+  double tr0 = now_s();
+  rank4n<> *r = new rank4n<>(bwt, (unsigned long)m, (unsigned)g_threads);
+  g_rank_seconds = now_s() - tr0;
   buffered_gap_array *gap = new buffered_gap_array(m + 1, base + ".excess");
   std::vector<long> ir(init_ranks, init_ranks + n_threads);
   silence(true);
+  double t0 = now_s();
   compute_gap<int>(r, gap, tb, te, n, n_threads, i0, 1L << 21, (unsigned char)last, ir, text_fn, base, gt_in_mf, gt_out_mf);
+  g_last_seconds = now_s() - t0;
   silence(false);
   gap_to_values(gap, gap_out);
   memset(gt_out, 0, (te - tb + 7) / 8);
@@ -116,7 +130,9 @@ int ref_compute_gap(const uint8_t *bwt, long m, long i0, int last, const uint8_t
 int ref_gap_to_bitvector(const uint64_t *gap, long m, const char *workdir, uint8_t *bv_out, long nbytes) {
   buffered_gap_array *g = gap_from_values(gap, m + 1, std::string(workdir) + "/ref_excess1");
   silence(true);
-  bitvector *bv = g->convert_to_bitvector(2);
+  double t0 = now_s();
+  bitvector *bv = g->convert_to_bitvector(g_threads);
+  g_last_seconds = now_s() - t0;
   silence(false);
   std::string fn = std::string(workdir) + "/ref_bv.bin";
   bv->save(fn);
@@ -212,7 +228,9 @@ int ref_merge(int H, const long *beg, const long *size, const int *const *psa, c
     }
     hbs.push_back(hb);
   }
+  double t0 = now_s();
   merge<int>(out_fn, ram_use, hbs);
+  g_last_seconds = now_s() - t0;
   silence(false);
   unsigned char *buf = NULL; long len = 0;
   utils::read_objects_from_file(buf, len, out_fn);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "psg_rank_query": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "psg_rank_free": (None, [_vp]),
     "psg_stream_gap": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_stream_gap_ctx": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_gap_to_bitvector": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "psg_merge_bwt": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, C.POINTER(_i64)]),
     "psg_split_gap": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -55,13 +56,21 @@ SIGNATURES = {
 }
 
 
+# include/psascan_amd_extras.h (bench / property-test input preparation, not the boundary)
+EXTRA_SIGNATURES = {
+    "psgx_gen_text": (_int, [_vp, _i64, _int, _int, C.c_uint64]),
+    "psgx_sort_halfblock": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
+    "psgx_check_sa5": (_int, [_vp, _i64, _vp, _i64, _i64, C.c_uint64, C.POINTER(_i64), C.POINTER(C.c_uint64)]),
+}
+
+
 def load_library(path=LIB_PATH):
     """dlopen the HIP library and bind every declared symbol (no device needed)."""
     if not os.path.exists(path):
         raise PsgError(-2, f"{path} not found -- run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
                            "psascan_amd has no CPU fallback")
     L = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA_SIGNATURES.items()):
         f = getattr(L, name)   # AttributeError if the symbol is missing
         f.restype = res
         f.argtypes = args

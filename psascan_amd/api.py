@@ -119,12 +119,14 @@ class StreamStats:
 
 
 def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_tail_end, d_gap, d_gt_out,
-               max_chains=0):
-    """One streaming pass (compute_gap<T>).  Returns (final_rank, StreamStats)."""
+               max_chains=0, right_context=0):
+    """One streaming pass (compute_gap<T>), optionally over a sub-range of the tail with
+    `right_context` bytes/bits of valid text/gt to its right.  Returns (final_rank, StreamStats)."""
     fin = C.c_int64(0)
     st = StreamStatsC()
-    check(lib().psg_stream_gap(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, _ptr(d_gt_in),
-                               rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains, C.byref(fin), C.byref(st)))
+    check(lib().psg_stream_gap_ctx(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context,
+                                   _ptr(d_gt_in), rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains,
+                                   C.byref(fin), C.byref(st)))
     return fin.value, StreamStats(st)
 
 

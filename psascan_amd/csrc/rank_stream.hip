@@ -242,7 +242,8 @@ __global__ __launch_bounds__(PSG_WG) void rank_query_kernel(RankView<CNT, B> R, 
 // ---------------------------------------------------------------------------------------
 struct StreamParams {
   const u8 *tail;
-  i64 T;
+  i64 T;              // tail_len + right context
+  i64 ctx;            // right context length (multiple of 64): steps u < ctx are not streamed
   const u32 *gt_in;
   u32 *gt_out;
   u32 *gap;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, Stre
   i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (gid >= P.nchains) return;
   i64 k = P.list ? P.list[gid] : gid;
-  i64 u0 = k * P.L;
+  i64 u0 = P.ctx + k * P.L;
   i64 u1 = std::min<i64>(u0 + P.L, P.T);
   i64 i = P.init[k];
   // text cursor: descending bytes starting at tail[T-1-u0]
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, Stre
         if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
       }
     }
-    if (P.gt_out) P.gt_out[w] = gout;
+    if (P.gt_out) P.gt_out[w - (P.ctx >> 5)] = gout;
   }
   P.fin[k] = i;
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, Stre
 struct WarmParams {
   const u8 *tail;
   i64 T;
+  i64 ctx;
   const u32 *gt_in;
   i64 i0;
   u32 last;
@@ -344,10 +346,11 @@ __global__ __launch_bounds__(PSG_WG) void warmup_kernel(RankView<CNT, B> R, Warm
   i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (gid >= P.nitems) return;
   i64 k = P.list ? P.list[gid] : gid;
-  i64 uend = k * P.L;                // the chain starts at step uend; warm-up covers [ubeg, uend)
+  i64 uend = P.ctx + k * P.L;        // the chain starts at step uend; warm-up covers [ubeg, uend)
   i64 ubeg = uend - P.W;
   i64 lo, hi;
-  if (ubeg <= 0) { ubeg = 0; lo = hi = P.rank_at_end; } else { lo = 0; hi = P.m; }
+  if (ubeg <= 0 && P.rank_at_end >= 0) { ubeg = 0; lo = hi = P.rank_at_end; }   // exact start
+  else { if (ubeg < 0) ubeg = 0; lo = 0; hi = P.m; }
   for (i64 u = ubeg; u < uend; ++u) {
     u32 c = P.tail[P.T - 1 - u];
     u32 g = P.gt_in ? (P.gt_in[u >> 5] >> (u & 31)) & 1u : 0u;
@@ -507,9 +510,17 @@ template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamPar
 extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                               const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out,
                               int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
+  return psg_stream_gap_ctx(r, i0, last_sym, d_tail, T, 0, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats);
+}
+
+extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
+                                  int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
+                                  uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
+  PSG_REQUIRE(ctx >= 0 && (ctx & 63) == 0, "psg_stream_gap_ctx: right context must be a multiple of 64");
   PSG_REQUIRE(r && d_gap, "psg_stream_gap: rank and gap required");
   PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");
-  PSG_REQUIRE(rank_at_end >= 0 && rank_at_end <= r->m, "psg_stream_gap: rank_at_tail_end out of range");
+  PSG_REQUIRE((rank_at_end >= 0 && rank_at_end <= r->m) || (rank_at_end == -1 && ctx > 0),
+              "psg_stream_gap: rank_at_tail_end out of range (-1 = unknown is only allowed with a right context)");
   psg_stream_stats st = {};
   if (T == 0) { if (h_final_rank) *h_final_rank = rank_at_end; if (stats) *stats = st; return 0; }
   PSG_REQUIRE(d_tail, "psg_stream_gap: tail text required");
@@ -531,7 +542,7 @@ extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, con
   PSG_HIP(hipMemsetAsync(flag_d.p, 0, 4, stream()));
   std::vector<i64> lo(K), hi(K), fin(K, -1), list;
   std::vector<char> resolved(K, 0), done(K, 0);
-  WarmParams WP{d_tail, T, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
+  WarmParams WP{d_tail, T + ctx, ctx, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
   // warm-up with growing W for the chains that did not resolve
   i64 nun = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
@@ -552,8 +563,9 @@ extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, con
     PSG_HIP(hipStreamSynchronize(stream()));
   }
   st.unresolved = nun;
+  if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
   bool check_ovf = T >= 0xFFFFFFFFll;
-  StreamParams SP{d_tail, T, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>()};
+  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>()};
   double kms = 0;
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
@@ -592,7 +604,7 @@ extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, con
       set_error("stream: chain hand-over check failed at chain " + std::to_string(k) + " (fin=" + std::to_string(fin[k - 1]) + " init=" + std::to_string(lo[k]) + ")");
       return PSG_ECHECK;
     }
-  if (lo[0] != rank_at_end) { set_error("stream: chain 0 did not start at rank_at_tail_end"); return PSG_ECHECK; }
+  if (ctx == 0 && lo[0] != rank_at_end) { set_error("stream: chain 0 did not start at rank_at_tail_end"); return PSG_ECHECK; }
   int ovf = 0;
   PSG_HIP(hipMemcpyAsync(&ovf, flag_d.p, 4, hipMemcpyDeviceToHost, stream()));
   total_tm.stop();
