@@ -42,7 +42,8 @@ int psg_init(int device);                 /* select device, create the stream   
 const char *psg_last_error(void);
 int psg_device_name(char *buf, int cap);
 int psg_malloc(void **d_ptr, int64_t bytes);
-int psg_free(void *d_ptr);
+int psg_free(void *d_ptr);                /* returns the block to the library's cache       */
+int psg_trim(void);                       /* gives all cached device memory back to the driver */
 int psg_memset(void *d_ptr, int value, int64_t bytes);
 int psg_h2d(void *d_dst, const void *h_src, int64_t bytes);
 int psg_d2h(void *h_dst, const void *d_src, int64_t bytes);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "psg_device_name": (_int, [C.c_char_p, _int]),
     "psg_malloc": (_int, [C.POINTER(_vp), _i64]),
     "psg_free": (_int, [_vp]),
+    "psg_trim": (_int, []),
     "psg_memset": (_int, [_vp, _int, _i64]),
     "psg_h2d": (_int, [_vp, _vp, _i64]),
     "psg_d2h": (_int, [_vp, _vp, _i64]),

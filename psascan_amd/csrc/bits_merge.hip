@@ -430,8 +430,8 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
 
 extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
   if (!p) return;
-  for (void *q : p->owned) (void)hipFree(q);
-  if (p->d_levels) (void)hipFree(p->d_levels);
+  for (void *q : p->owned) psg::pool_free(q);
+  if (p->d_levels) psg::pool_free(p->d_levels);
   delete p;
 }
 
@@ -455,7 +455,7 @@ extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_pl
       L.mbv = hbs[h].d_mbv; L.nbits = nh[h];
       i64 ntiles = cdiv(L.nbits, TILE_B);
       void *samp = nullptr; DevBuf tot;
-      hipError_t e = hipMalloc(&samp, (size_t)(ntiles + 1) * 8);
+      hipError_t e = psg::pool_alloc(&samp, (size_t)(ntiles + 1) * 8);
       if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
       p->owned.push_back(samp);
       if ((rc = tot.alloc(8))) { psg_merge_plan_free(p); return rc; }
@@ -474,7 +474,7 @@ extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_pl
     }
     p->levels.push_back(L);
   }
-  hipError_t e = hipMalloc((void **)&p->d_levels, sizeof(MergeLevel) * (size_t)H);
+  hipError_t e = psg::pool_alloc((void **)&p->d_levels, sizeof(MergeLevel) * (size_t)H);
   if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
   e = hipMemcpyAsync(p->d_levels, p->levels.data(), sizeof(MergeLevel) * (size_t)H, hipMemcpyHostToDevice, stream());
   hipError_t e3 = hipStreamSynchronize(stream());

@@ -34,6 +34,13 @@ void note_kernel_ms(double ms);
     if (!(cond)) { psg::set_error(std::string("invalid argument: ") + msg); return PSG_EINVAL; } \
   } while (0)
 
+// caching device allocator: hipMalloc/hipFree of multi-GiB buffers cost ~100s of ms each
+// (page-table work + implicit sync); freed blocks are kept and reused (single stream =>
+// stream-ordered reuse is safe).  pool_trim() returns everything to the driver.
+hipError_t pool_alloc(void **p, size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+
 // RAII device buffer for temporaries
 struct DevBuf {
   void *p = nullptr;
@@ -41,11 +48,11 @@ struct DevBuf {
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) psg::pool_free(p); }
   int alloc(i64 b) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { psg::pool_free(p); p = nullptr; }
     bytes = b < 16 ? 16 : b;
-    hipError_t e = hipMalloc(&p, (size_t)bytes);
+    hipError_t e = psg::pool_alloc(&p, (size_t)bytes);
     if (e != hipSuccess) { p = nullptr; psg::set_error(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e)); return PSG_ENOMEM; }
     return 0;
   }

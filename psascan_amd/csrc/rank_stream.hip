@@ -426,7 +426,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   r->blocks_bytes = r->nblk * (i64)r->stride;
   int rc = 0;
   DevBuf code_d, seg_cnt, group_sum;
-  hipError_t e = hipMalloc((void **)&r->d_blocks, (size_t)r->blocks_bytes);
+  hipError_t e = psg::pool_alloc((void **)&r->d_blocks, (size_t)r->blocks_bytes);
   if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
   PSG_HIP(hipMemcpyAsync(code_d.p, r->code, 256, hipMemcpyHostToDevice, stream()));
@@ -447,7 +447,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
 
 extern "C" void psg_rank_free(psg_rank_t *r) {
   if (!r) return;
-  if (r->d_blocks) (void)hipFree(r->d_blocks);
+  if (r->d_blocks) psg::pool_free(r->d_blocks);
   delete r;
 }
 extern "C" int psg_rank_counts(const psg_rank_t *r, int64_t counts[256]) {

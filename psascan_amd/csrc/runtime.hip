@@ -1,7 +1,10 @@
 // runtime.hip -- device selection, memory helpers, error state, small bit utilities.
 #include "dev_common.hpp"
 
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace psg {
 static thread_local std::string g_err;
@@ -13,6 +16,58 @@ static double g_last_ms = 0;
 void set_error(const std::string &s) { g_err = s; }
 hipStream_t stream() { return g_stream; }
 void note_kernel_ms(double ms) { g_last_ms = ms; }
+
+// ---- caching allocator ------------------------------------------------------------------
+static std::mutex g_pool_mu;
+static std::multimap<size_t, void *> g_pool_free;      // size -> block
+static std::unordered_map<void *, size_t> g_pool_live;  // block -> size
+
+static size_t pool_round(size_t b) {
+  size_t g = b >= (1u << 20) ? (size_t)(2u << 20) : (size_t)4096;
+  return (b + g - 1) / g * g;
+}
+
+hipError_t pool_alloc(void **p, size_t bytes) {
+  size_t need = pool_round(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_free.lower_bound(need);
+    if (it != g_pool_free.end() && it->first <= need + need / 4) {
+      *p = it->second;
+      g_pool_live[*p] = it->first;
+      g_pool_free.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess) {  // give cached blocks back and retry once
+    (void)hipGetLastError();
+    pool_trim();
+    e = hipMalloc(p, need);
+  }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_live[*p] = need; }
+  return e;
+}
+
+void pool_free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool_live.find(p);
+  if (it == g_pool_live.end()) { (void)hipFree(p); return; }
+  g_pool_free.emplace(it->second, p);
+  g_pool_live.erase(it);
+}
+
+void pool_trim() {
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : g_pool_free) blocks.push_back(kv.second);
+    g_pool_free.clear();
+  }
+  if (!blocks.empty() && g_stream) (void)hipStreamSynchronize(g_stream);
+  for (void *b : blocks) (void)hipFree(b);
+}
 
 // ---- single-workgroup scan ------------------------------------------------------------
 __global__ __launch_bounds__(1024) void scan_u64_kernel(u64 *vals, i64 n, u64 *total) {
@@ -123,11 +178,12 @@ int psg_device_name(char *buf, int cap) {
 
 int psg_malloc(void **d_ptr, int64_t bytes) {
   PSG_REQUIRE(d_ptr && bytes >= 0, "psg_malloc");
-  hipError_t e = hipMalloc(d_ptr, (size_t)(bytes < 16 ? 16 : bytes));
+  hipError_t e = psg::pool_alloc(d_ptr, (size_t)(bytes < 16 ? 16 : bytes));
   if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); *d_ptr = nullptr; return e == hipErrorOutOfMemory ? PSG_ENOMEM : PSG_EDEVICE; }
   return 0;
 }
-int psg_free(void *d_ptr) { if (d_ptr) PSG_HIP(hipFree(d_ptr)); return 0; }
+int psg_free(void *d_ptr) { if (d_ptr) psg::pool_free(d_ptr); return 0; }
+int psg_trim(void) { psg::pool_trim(); return 0; }
 int psg_memset(void *d_ptr, int value, int64_t bytes) {
   if (bytes > 0) PSG_HIP(hipMemsetAsync(d_ptr, value, (size_t)bytes, stream()));
   return 0;

@@ -1,0 +1,95 @@
+// membench.hip -- what the MI355X memory system gives the access pattern of the stream kernel.
+//   hipcc --offload-arch=gfx950 -O3 -o membench membench.hip && ./membench [table_GiB] [atomic_GiB]
+// Reports (a) streaming read GB/s, (b) dependent random 16-byte loads/s (1 and 2 per step),
+// (c) random no-return u32 atomic adds/s, (d) 2 loads + 1 atomic per step (the stream kernel's
+// shape: counter sector + data sector + gap increment).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+
+__global__ void fill_kernel(uint4 *p, size_t n16) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) {
+    uint64_t a = mix(k), b = mix(a);
+    p[k] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *p, size_t n16, uint32_t *sink) {
+  uint32_t acc = 0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) {
+    uint4 v = p[k]; acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678) *sink = acc;
+}
+
+// LOADS dependent random 16-byte loads per step (+ optional atomic), `steps` steps per lane
+template <int LOADS, bool ATOMIC, int STRIDE16>
+__global__ __launch_bounds__(256) void chase_kernel(const uint4 *tab, size_t nrows, uint32_t *cnt, size_t ncnt, int steps, uint32_t *sink) {
+  uint64_t s = mix((uint64_t)blockIdx.x * 256 + threadIdx.x);
+  uint32_t acc = 0;
+  for (int t = 0; t < steps; ++t) {
+    uint64_t r = s % nrows;
+    uint4 v = tab[r * STRIDE16];
+    uint32_t x = v.x;
+    if (LOADS == 2) { uint4 w = tab[r * STRIDE16 + STRIDE16 - 1]; x ^= w.y; }   // far end of the same row: another sector
+    acc += x;
+    s = mix(s ^ x);                                                               // next address depends on the data
+    if (ATOMIC) atomicAdd(&cnt[(s >> 20) % ncnt], 1u);
+  }
+  if (acc == 0x12345678) *sink = acc;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void atomic_kernel(uint32_t *cnt, size_t ncnt, int steps) {
+  uint64_t s = mix((uint64_t)blockIdx.x * 256 + threadIdx.x);
+  for (int t = 0; t < steps; ++t) { s = mix(s); atomicAdd(&cnt[s % ncnt], 1u); }
+}
+
+template <class F> static double time_ms(F f, int reps = 3) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int r = 0; r < reps; ++r) f();
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main(int argc, char **argv) {
+  double tab_gib = argc > 1 ? atof(argv[1]) : 34.0, cnt_gib = argc > 2 ? atof(argv[2]) : 8.0;
+  size_t tab_bytes = (size_t)(tab_gib * (1ull << 30)), cnt_bytes = (size_t)(cnt_gib * (1ull << 30));
+  uint4 *tab; uint32_t *cnt, *sink;
+  CK(hipMalloc(&tab, tab_bytes)); CK(hipMalloc(&cnt, cnt_bytes)); CK(hipMalloc(&sink, 4));
+  size_t n16 = tab_bytes / 16;
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, tab, n16);
+  CK(hipMemset(cnt, 0, cnt_bytes)); CK(hipDeviceSynchronize());
+  printf("table %.1f GiB, counters %.1f GiB\n", tab_gib, cnt_gib);
+  double ms = time_ms([&] { hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0, 0, tab, n16, sink); });
+  printf("streaming read            : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  const int steps = 512;
+  const size_t lanes = 256ull * 32 * 64;   // 8 waves/SIMD on 256 CUs
+  const int grid = (int)(lanes / 256);
+  // rows of 1088 B (= 68 x 16 B): counter sector at the start, data sector at the end -- the rank block shape
+  size_t nrows = n16 / 68;
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, false, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
+  printf("dependent random loads x1 : %8.2f G steps/s  (%.1f ns/step/lane)\n", lanes * steps / ms / 1e6, ms * 1e6 / steps);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, false, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
+  printf("dependent random loads x2 : %8.2f G steps/s  (%.1f ns/step/lane)\n", lanes * steps / ms / 1e6, ms * 1e6 / steps);
+  ms = time_ms([&] { hipLaunchKernelGGL((atomic_kernel<1>), dim3(grid), dim3(256), 0, 0, cnt, cnt_bytes / 4, steps); });
+  printf("random u32 atomics        : %8.2f G atomics/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, true, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
+  printf("1 load + 1 atomic / step  : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, true, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
+  printf("2 loads + 1 atomic / step : %8.2f G steps/s   <- stream kernel shape\n", lanes * steps / ms / 1e6);
+  // half the lanes (4 waves/SIMD) to see the latency/occupancy dependence
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, true, 68>), dim3(grid / 2), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
+  printf("  same at 4 waves/SIMD    : %8.2f G steps/s\n", lanes / 2 * steps / ms / 1e6);
+  return 0;
+}
