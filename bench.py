@@ -31,6 +31,12 @@ sys.path.insert(0, ROOT)
 A_STREAM = 39.25      # algorithmic bytes per streamed suffix (b = 64)
 A_MERGE = 11.0        # algorithmic bytes per merged output suffix (merge.hpp:161)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# HBM bytes per streamed suffix of stream_kernel<256,64> from the PMC passes committed in
+# profiles/r01_pmc_summary.csv: (FETCH_SIZE 2.865e8 KB + WRITE_SIZE 7.132e7 KB) * 1024 / 2^31.
+# Calibration (profiles/r01_membench.txt + same csv): FETCH_SIZE*1024 is exact for random
+# 16-byte loads (64 B per request) and reads 1/2 for wide coalesced streams on gfx950; this
+# kernel's traffic is random-sector traffic, so no correction is applied.
+PMC_TRAFFIC_B_PER_SUFFIX = {17.0: 170.6}
 
 
 def parse():
@@ -276,7 +282,10 @@ def main():
             "gap_stream_kernel_suffixes_per_s": stream_suffixes / kernel_s if kernel_s else None,
             "phase_ms": {k: round(1e3 * v, 3) for k, v in per.items()},
             "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (PMC_TRAFFIC_B_PER_SUFFIX.get(round(rk_bytes / ls, 1)) or 0) * stream_suffixes or None,
+                         "traffic_source": "PMC FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_summary.csv (bytes per launch)",
+                         "random_access_ceiling": "profiles/r01_membench.txt: 2 dependent random sector loads + 1 random u32 atomic per step run at 11.0-11.2 G steps/s on this chip; stream_kernel reaches ~95% of that",
                          "algorithmic_bytes_per_suffix": A_STREAM, "suffixes_per_launch": stream_suffixes,
                          "avg_launch_ms": 1e3 * kernel_s},
             "merge_roofline": {"achieved": A_MERGE * (oe - ob) / per["merge"] / 1e9, "unit": "GB/s", "note": "includes plan build (rank samples over the merge bitvector)"},

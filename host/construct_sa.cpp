@@ -1,0 +1,332 @@
+// construct_sa -- drop-in for the reference's command line (src/main.cpp:48-246) with the
+// streaming-gap + merge path running on an MI355X through the C ABI (include/psascan_amd.h).
+//
+//   construct_sa [-g GAPFILE] [-m MEM] [-o OUTFILE] [-v] [-h] FILE        (same flags, same defaults)
+//   extension:   --block-size N   force max_block_size (bypasses the -m formula; for tests)
+//                --chains N       cap the number of backward-search chains per pass
+//
+// The block schedule is the reference's process_block (partial_sufsort.hpp:67-551) and pSAscan
+// driver (psascan.hpp:53-131): same block / half-block boundaries for the same -m and thread
+// count, so the same passes are executed.  The per-half-block suffix sort stays on the host
+// (halfblock.hpp); every hot-path step is a psg_* call.  Output: 5*n bytes, 40-bit LE entries.
+#include <getopt.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/psascan_amd.h"
+#include "halfblock.hpp"
+
+using psa_host::HalfBlock;
+
+static const char *program_name = "construct_sa";
+static bool g_verbose = false;
+
+static double wclock() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec + t.tv_usec * 1e-6; }
+
+static void usage(int status) {
+  printf("Usage: %s [OPTION]... FILE\n"
+         "Construct the suffix array of text stored in FILE.\n"
+         "\n"
+         "Mandatory arguments to long options are mandatory for short options too.\n"
+         "  -h, --help              display this help and exit\n"
+         "  -g, --gap=GAPFILE       accepted for compatibility (prefix of the reference's temporary\n"
+         "                          files; this implementation keeps intermediates in HBM)\n"
+         "  -m, --mem=MEM           memory budget in bytes that determines the block size exactly as\n"
+         "                          in the reference. Metric and IEC suffixes are recognized, e.g.,\n"
+         "                          -m 10k, -m 1Mi, -m 3G. Default: 3584Mi\n"
+         "  -o, --output=OUTFILE    specify output filename. Default: FILE.sa5\n"
+         "  -v, --verbose           print detailed information\n"
+         "      --block-size=N      force the maximal block size (extension)\n"
+         "      --chains=N          cap the number of chains per streaming pass (extension)\n",
+         program_name);
+  std::exit(status);
+}
+
+// digits + optional k|m|g|t (decimal) or ki|mi|gi|ti (binary), case-insensitive (main.cpp:76-131)
+static bool parse_number(const char *str, uint64_t *ret) {
+  *ret = 0;
+  size_t len = strlen(str), nd = 0;
+  while (nd < len && isdigit((unsigned char)str[nd])) { *ret = *ret * 10 + (uint64_t)(str[nd] - '0'); ++nd; }
+  if (nd == 0) return false;
+  size_t sl = len - nd;
+  if (sl == 0) return true;
+  if (sl > 2) return false;
+  char a = (char)tolower((unsigned char)str[nd]);
+  if (sl == 2 && tolower((unsigned char)str[nd + 1]) != 'i') return false;
+  int idx = a == 'k' ? 1 : a == 'm' ? 2 : a == 'g' ? 3 : a == 't' ? 4 : 0;
+  if (!idx) return false;
+  if (sl == 1) { for (int k = 0; k < idx; ++k) *ret *= 1000; } else *ret <<= (10 * idx);
+  return true;
+}
+
+static bool file_exists(const std::string &f) { FILE *fp = fopen(f.c_str(), "r"); if (fp) fclose(fp); return fp != nullptr; }
+
+#define CK(call)                                                                                      \
+  do { int rc_ = (call); if (rc_ != 0) throw std::runtime_error(std::string(#call) + ": " + psg_last_error()); } while (0)
+
+struct Dev {  // owning device buffer
+  void *p = nullptr;
+  int64_t bytes = 0;
+  Dev() {}
+  explicit Dev(int64_t b, bool zero = false) { alloc(b, zero); }
+  Dev(const Dev &) = delete;
+  Dev &operator=(const Dev &) = delete;
+  Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
+  Dev &operator=(Dev &&o) noexcept { release(); p = o.p; bytes = o.bytes; o.p = nullptr; return *this; }
+  ~Dev() { release(); }
+  void alloc(int64_t b, bool zero = false) { release(); bytes = b < 16 ? 16 : b; CK(psg_malloc(&p, bytes)); if (zero) CK(psg_memset(p, 0, bytes)); }
+  void release() { if (p) { psg_free(p); p = nullptr; } }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct DevHalfBlock { int64_t beg, size; Dev psa_lo, psa_hi, mbv; };
+
+static Dev upload(const void *h, int64_t bytes, int64_t pad = 16) {
+  Dev d((bytes + pad - 1) / pad * pad + pad, true);
+  if (bytes) CK(psg_h2d(d.p, h, bytes));
+  return d;
+}
+
+static void log_phase(const char *what, double t0, int64_t units = 0) {
+  double dt = wclock() - t0;
+  if (units) fprintf(stderr, "    %s: %.2fs (%.2f MiB/s)\n", what, dt, units / 1048576.0 / std::max(dt, 1e-9));
+  else fprintf(stderr, "    %s: %.2fs\n", what, dt);
+}
+
+static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, int64_t forced_block,
+                int64_t max_chains) {
+  // ---- planner: psascan.hpp:57-91 ----
+  if (ram_use < 6) throw std::runtime_error("not enough memory to run pSAscan.");
+  FILE *f = fopen(text_fn.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open " + text_fn);
+  fseek(f, 0, SEEK_END);
+  int64_t n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> text((size_t)n);
+  if (n && fread(text.data(), 1, (size_t)n, f) != (size_t)n) throw std::runtime_error("short read on " + text_fn);
+  fclose(f);
+  fprintf(stderr, "Input filename = %s\nOutput filename = %s\nInput length = %ld (%.1fMiB)\n\n", text_fn.c_str(), out_fn.c_str(), (long)n, n / 1048576.0);
+  const int64_t g = 1 << 21;
+  int64_t ram_for_threads = 2 * max_threads * g;
+  if ((long double)ram_use / 5.2L < (long double)(1LL << 31)) ram_for_threads += max_threads * g;
+  else ram_for_threads += (int64_t)(((4.L / 5) * max_threads) * g);
+  ram_for_threads += max_threads * g + max_threads * (int64_t)(6 << 20);
+  int64_t max_block_size;
+  if (forced_block > 0) max_block_size = std::max<int64_t>(2, forced_block);
+  else {
+    int64_t excl = (int64_t)ram_use - ram_for_threads;
+    if (excl < 6) {
+      long req = (long)((ram_for_threads + (1 << 20) - 1) / (1 << 20));
+      fprintf(stderr, "Error: not enough memory to start threads. You need at least %ldMiB\n", req + 1);
+      std::exit(EXIT_FAILURE);
+    }
+    max_block_size = std::max<int64_t>(2, (int64_t)(excl / 5.2L));
+  }
+  fprintf(stderr, "RAM budget = %lu (%.1fMiB)\nMax block size = %ld (%.1fMiB)\n\n", (unsigned long)ram_use, ram_use / 1048576.0, (long)max_block_size, max_block_size / 1048576.0);
+  double start = wclock();
+  FILE *out = fopen(out_fn.c_str(), "wb");
+  if (!out) throw std::runtime_error("cannot open output " + out_fn);
+  if (n == 0) { fclose(out); return; }
+
+  CK(psg_init(0));
+  char devname[256];
+  CK(psg_device_name(devname, sizeof devname));
+  fprintf(stderr, "Device = %s\n\n", devname);
+  Dev d_text = upload(text.data(), n);
+  const int64_t gt_words = (n + 31) / 32 + 2;
+  Dev gt_cur(4 * gt_words, true), gt_new(4 * gt_words, true);
+  std::vector<DevHalfBlock> hbs;
+  std::vector<uint32_t> cur_host;
+
+  auto up_hb = [&](const HalfBlock &h) {
+    DevHalfBlock d;
+    d.beg = h.beg; d.size = h.size;
+    d.psa_lo = upload(h.psa_lo.data(), 4 * h.size);
+    if (!h.psa_hi.empty()) d.psa_hi = upload(h.psa_hi.data(), h.size);
+    return d;
+  };
+
+  const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
+  for (int64_t bid = n_blocks - 1; bid >= 0; --bid) {   // partial_sufsort.hpp:568
+    const int64_t b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
+    const bool last_block = e == n;
+    if (!last_block && bs <= 1) throw std::runtime_error("any block other than the last has to be of length at least two.");
+    const int64_t ls = last_block ? std::min<int64_t>(bs, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, bs / 2);
+    const int64_t rs = bs - ls, mid = b + ls;
+    fprintf(stderr, "Process block %ld/%ld [%ld..%ld):\n", (long)(n_blocks - bid), (long)n_blocks, (long)b, (long)e);
+    CK(psg_memset(gt_new.p, 0, gt_new.bytes));
+    if (!last_block) { cur_host.resize((size_t)gt_words); CK(psg_d2h(cur_host.data(), gt_cur.p, 4 * gt_words)); }
+    auto gt_tail_e = [&](int64_t v) { int64_t idx = n - (e + v); return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u); };
+    HalfBlock R, L;
+    double t0 = wclock();
+    if (rs > 0) {
+      psa_host::sort_halfblock(text.data(), n, mid, e, gt_tail_e, R);
+      log_phase("host sufsort (right half)", t0, rs);
+    }
+    auto gt_tail_mid = [&](int64_t v) {  // position mid+v in (mid, e]: right half's gt_begin, u = e - j
+      if (rs == 0) return gt_tail_e(v);
+      int64_t u = e - (mid + v);
+      return (bool)((R.gt_begin[(size_t)(u >> 5)] >> (u & 31)) & 1u);
+    };
+    t0 = wclock();
+    psa_host::sort_halfblock(text.data(), n, b, mid, gt_tail_mid, L);
+    log_phase("host sufsort (left half)", t0, ls);
+    Dev d_lgt = upload(L.gt_begin.data(), 4 * (int64_t)L.gt_begin.size());
+    DevHalfBlock hbL = up_hb(L);
+    if (rs == 0) {
+      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      hbs.push_back(std::move(hbL));
+      std::swap(gt_cur, gt_new);
+      continue;
+    }
+    DevHalfBlock hbR = up_hb(R);
+    Dev d_lbwt = upload(L.bwt.data(), ls), d_rbwt = upload(R.bwt.data(), rs);
+    Dev d_rgt = upload(R.gt_begin.data(), 4 * (int64_t)R.gt_begin.size());
+    // ---- pass A (partial_sufsort.hpp:403-414)
+    t0 = wclock();
+    psg_rank_t *rankL = nullptr;
+    CK(psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL));
+    log_phase("Construct rank (left half, device)", t0, ls);
+    Dev gapA(4 * (ls + 2), true), gtA(4 * ((rs + 31) / 32 + 2), true);
+    int64_t initA = psa_host::rank_by_search(text.data(), n, L, e);
+    psg_stream_stats st;
+    t0 = wclock();
+    CK(psg_stream_gap(rankL, L.i0, text[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
+                      gtA.as<uint32_t>(), max_chains, nullptr, &st));
+    log_phase("Stream (right half through left half, device)", t0, rs);
+    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
+    psg_rank_free(rankL);
+    Dev bvA(4 * ((bs + 31) / 32 + 2), true);
+    int64_t nb = 0;
+    CK(psg_gap_to_bitvector(gapA.as<uint32_t>(), ls, bvA.as<uint32_t>(), bs, &nb));
+    if (nb != bs) throw std::runtime_error("gap sum mismatch after pass A");
+    gapA.release();
+    if (last_block) {  // :418-429 -- the left half's gap array is its merge bitvector
+      hbL.mbv = std::move(bvA);
+      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
+      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
+      std::swap(gt_cur, gt_new);
+      continue;
+    }
+    // ---- BWT merge (:468-471)
+    t0 = wclock();
+    Dev d_bbwt(bs + 16);
+    int64_t block_i0 = -1;
+    CK(psg_merge_bwt(d_lbwt.as<uint8_t>(), d_rbwt.as<uint8_t>(), ls, rs, L.i0, R.i0, text[(size_t)mid - 1], bvA.as<uint32_t>(), d_bbwt.as<uint8_t>(), &block_i0));
+    d_lbwt.release(); d_rbwt.release();
+    log_phase("Merge BWTs of half-blocks (device)", t0, bs);
+    // ---- pass B (:500-514)
+    t0 = wclock();
+    psg_rank_t *rankB = nullptr;
+    CK(psg_rank_build(d_bbwt.as<uint8_t>(), bs, 0, &rankB));
+    d_bbwt.release();
+    log_phase("Construct rank (block, device)", t0, bs);
+    const int64_t T = n - e;
+    Dev gapB(4 * (bs + 2), true);
+    t0 = wclock();
+    CK(psg_stream_gap(rankB, block_i0, text[(size_t)e - 1], d_text.as<uint8_t>() + e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
+                      gt_new.as<uint32_t>(), max_chains, nullptr, &st));
+    log_phase("Stream (tail through block, device)", t0, T);
+    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
+    psg_rank_free(rankB);
+    CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
+    CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+    // ---- split (:536-542)
+    t0 = wclock();
+    hbL.mbv.alloc(4 * ((bs + T + 31) / 32 + 2));
+    hbR.mbv.alloc(4 * ((rs + T + 31) / 32 + 2));
+    CK(psg_split_gap(gapB.as<uint32_t>(), bvA.as<uint32_t>(), ls, rs, T, hbL.mbv.as<uint32_t>(), hbR.mbv.as<uint32_t>()));
+    log_phase("Compute gaps of half-blocks (device)", t0, bs);
+    hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
+    std::swap(gt_cur, gt_new);
+  }
+  gt_cur.release(); gt_new.release(); d_text.release();
+  std::vector<uint8_t>().swap(text);
+
+  // ---- merge (psascan.hpp:117-125, merge.hpp:55-180)
+  fprintf(stderr, "\nMerge partial suffix arrays:\n");
+  double t0 = wclock();
+  std::sort(hbs.begin(), hbs.end(), [](const DevHalfBlock &a, const DevHalfBlock &b) { return a.beg < b.beg; });
+  std::vector<psg_hb_desc> desc(hbs.size());
+  for (size_t h = 0; h < hbs.size(); ++h)
+    desc[h] = psg_hb_desc{hbs[h].beg, hbs[h].size, hbs[h].psa_lo.as<uint32_t>(), hbs[h].psa_hi.as<uint8_t>(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
+  psg_merge_plan_t *plan = nullptr;
+  CK(psg_merge_plan_create(desc.data(), (int)desc.size(), &plan));
+  const int64_t slice = 64LL << 20;  // output entries per slice
+  Dev d_out(5 * std::min(slice, n) + 16);
+  std::vector<uint8_t> h_out((size_t)(5 * std::min(slice, n)));
+  for (int64_t x = 0; x < n; x += slice) {
+    int64_t cnt = std::min(slice, n - x);
+    CK(psg_merge_run(plan, x, cnt, d_out.as<uint8_t>()));
+    CK(psg_d2h(h_out.data(), d_out.p, 5 * cnt));
+    if (fwrite(h_out.data(), 1, (size_t)(5 * cnt), out) != (size_t)(5 * cnt)) throw std::runtime_error("write failed on " + out_fn);
+  }
+  psg_merge_plan_free(plan);
+  fclose(out);
+  log_phase("merge + write", t0, 5 * n);
+  double total = wclock() - start;
+  fprintf(stderr, "\n\nComputation finished. Summary:\n  elapsed time: %.2fs (%.4fs/MiB)\n  speed: %.2fMiB/s\n", total, total / (n / 1048576.0), (n / 1048576.0) / total);
+}
+
+int main(int argc, char **argv) {
+  program_name = argv[0];
+  static struct option long_options[] = {{"help", no_argument, NULL, 'h'}, {"gap", required_argument, NULL, 'g'}, {"mem", required_argument, NULL, 'm'},
+                                         {"output", required_argument, NULL, 'o'}, {"verbose", no_argument, NULL, 'v'},
+                                         {"block-size", required_argument, NULL, 1000}, {"chains", required_argument, NULL, 1001}, {NULL, 0, NULL, 0}};
+  uint64_t ram_use = (uint64_t)3584 << 20;
+  std::string output_filename, gap_filename;
+  int64_t forced_block = 0, max_chains = 0;
+  int c;
+  while ((c = getopt_long(argc, argv, "g:hm:o:v", long_options, NULL)) != -1) {
+    switch (c) {
+      case 'g': gap_filename = optarg; break;
+      case 'h': usage(EXIT_FAILURE); break;             // the reference exits with failure here too (main.cpp:159-161)
+      case 'm':
+        if (!parse_number(optarg, &ram_use)) { fprintf(stderr, "Error: parsing RAM limit (%s) failed\n\n", optarg); usage(EXIT_FAILURE); }
+        if (ram_use == 0) { fprintf(stderr, "Error: invalid RAM limit (%lu)\n\n", (unsigned long)ram_use); usage(EXIT_FAILURE); }
+        break;
+      case 'o': output_filename = optarg; break;
+      case 'v': g_verbose = true; break;
+      case 1000: { uint64_t v; if (!parse_number(optarg, &v) || v == 0) { fprintf(stderr, "Error: bad --block-size\n\n"); usage(EXIT_FAILURE); } forced_block = (int64_t)v; break; }
+      case 1001: max_chains = atoll(optarg); break;
+      default: usage(EXIT_FAILURE); break;
+    }
+  }
+  if (optind >= argc) { fprintf(stderr, "Error: FILE not provided\n\n"); usage(EXIT_FAILURE); }
+  std::string text_filename = argv[optind++];
+  if (optind < argc) fprintf(stderr, "Warning: multiple input files provided. Only the first will be processed.\n");
+  if (output_filename.empty()) output_filename = text_filename + ".sa5";
+  if (gap_filename.empty()) gap_filename = output_filename;
+  if (!file_exists(text_filename)) { fprintf(stderr, "Error: input file (%s) does not exist\n\n", text_filename.c_str()); usage(EXIT_FAILURE); }
+  if (file_exists(output_filename)) {   // main.cpp:216-238
+    char *line = NULL; size_t buflen = 0; ssize_t len = 0;
+    do {
+      printf("Output file (%s) exists. Overwrite? [y/n]: ", output_filename.c_str());
+      if ((len = getline(&line, &buflen, stdin)) == -1) { printf("\nError: failed to read answer\n\n"); fflush(stdout); usage(EXIT_FAILURE); }
+    } while (len != 2 || (line[0] != 'y' && line[0] != 'n'));
+    if (line[0] == 'n') { free(line); std::exit(EXIT_FAILURE); }
+    free(line);
+  }
+  long max_threads = 0;
+  if (const char *e = getenv("OMP_NUM_THREADS")) max_threads = atol(e);   // the reference's only thread knob (main.cpp:241)
+  if (max_threads <= 0) max_threads = (long)std::max(1u, std::thread::hardware_concurrency());
+  try {
+    run(text_filename, output_filename, ram_use, max_threads, forced_block, max_chains);
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "Error: %s\n", ex.what());
+    if (file_exists(output_filename)) remove(output_filename.c_str());
+    return EXIT_FAILURE;
+  }
+  return 0;
+}

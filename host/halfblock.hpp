@@ -1,0 +1,119 @@
+// halfblock.hpp -- host-side suffix sort of one half-block [beg,end) of the text, ordered as
+// suffixes of the WHOLE text.  Produces what the reference's in-memory pSAscan hands to
+// process_block (inmem_psascan_src/inmem_psascan.hpp:64-304 as used at
+// partial_sufsort.hpp:166,286): partial SA, BWT (dummy 0 at i0, inmem_bwt_from_sa.hpp:51-54),
+// i0 and the gt_begin bits.  north_star keeps this step on host cores.
+//
+// Ties that run past `end` are decided the way the reference does it: the block is renamed with
+// the gt bits of its positions w.r.t. `end` (idea of initial_partial_sufsort.hpp:61-80: symbols
+// above the block's last symbol, and occurrences of the last symbol followed by a suffix greater
+// than text[end..), move up by one), after which a plain suffix sorter yields the true order.
+// This is why byte 255 is not allowed in the input (same restriction as the reference,
+// initial_partial_sufsort.hpp:141-146).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <vector>
+
+#include "sais.hpp"
+
+namespace psa_host {
+
+struct HalfBlock {
+  int64_t beg = 0, size = 0, i0 = 0;
+  std::vector<uint32_t> psa_lo;
+  std::vector<uint8_t> psa_hi;     // only when size > 2^32
+  std::vector<uint8_t> bwt;
+  std::vector<uint32_t> gt_begin;  // bit u <-> position end-u, u in [0,size)
+};
+
+// gt_tail(v), v >= 1: [text[end+v..n) > text[end..n)]   (only asked for end+v < n)
+typedef std::function<bool(int64_t)> GtTail;
+
+// [text[s..n) > text[e..n)] for beg <= s < e = end, using text up to `end` and gt_tail beyond
+static inline bool gt_wrt_end(const uint8_t *text, int64_t n, int64_t s, int64_t e, const GtTail &gt_tail) {
+  int64_t lim = e - s;  // symbols of the s-suffix that lie before e
+  for (int64_t k = 0; k < lim; ++k) {
+    if (e + k >= n) return true;  // text[e..n) is a proper prefix of text[s..n)
+    uint8_t a = text[s + k], b = text[e + k];
+    if (a != b) return a > b;
+  }
+  // text[s..e) == text[e..e+lim): now text[e..) against text[e+lim..)
+  if (e + lim >= n) return true;
+  return !gt_tail(lim);
+}
+
+static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, int64_t end, const GtTail &gt_tail,
+                                  HalfBlock &out) {
+  const int64_t m = end - beg;
+  out.beg = beg; out.size = m;
+  std::vector<uint8_t> blk(text + beg, text + end);
+  bool renamed = false;
+  uint8_t last = blk[(size_t)m - 1];
+  bool gt_of_beg = false;  // [text[beg..) > text[end..)]
+  if (end < n) {
+    gt_of_beg = gt_wrt_end(text, n, beg, end, gt_tail);
+    renamed = true;
+    for (int64_t i = 0; i + 1 < m; ++i) {
+      uint8_t c = blk[(size_t)i];
+      if (c > last || (c == last && gt_wrt_end(text, n, beg + i + 1, end, gt_tail))) {
+        if (c == 255) throw std::runtime_error("the input contains byte 255");
+        blk[(size_t)i] = c + 1;
+      }
+    }
+    if (last == 255) throw std::runtime_error("the input contains byte 255");
+    blk[(size_t)m - 1] = last + 1;
+  } else {
+    for (int64_t i = 0; i < m; ++i) if (blk[(size_t)i] == 255) throw std::runtime_error("the input contains byte 255");
+  }
+  (void)renamed;
+  out.psa_lo.resize((size_t)m);
+  out.bwt.resize((size_t)m);
+  out.gt_begin.assign((size_t)((m + 31) / 32 + 1), 0);
+  if (m < (int64_t)1 << 31) {
+    std::vector<int32_t> sa((size_t)m);
+    Sais<int32_t>::run(blk.data(), sa.data(), (int32_t)m, 256);
+    for (int64_t k = 0; k < m; ++k) out.psa_lo[(size_t)k] = (uint32_t)sa[(size_t)k];
+  } else {
+    std::vector<int64_t> sa((size_t)m);
+    Sais<int64_t>::run(blk.data(), sa.data(), m, (int64_t)256);
+    out.psa_hi.resize((size_t)m);
+    for (int64_t k = 0; k < m; ++k) { out.psa_lo[(size_t)k] = (uint32_t)sa[(size_t)k]; out.psa_hi[(size_t)k] = (uint8_t)(sa[(size_t)k] >> 32); }
+  }
+  std::vector<uint8_t>().swap(blk);
+  auto pos = [&](int64_t k) { return (int64_t)out.psa_lo[(size_t)k] | (out.psa_hi.empty() ? 0 : (int64_t)out.psa_hi[(size_t)k] << 32); };
+  for (int64_t k = 0; k < m; ++k) if (pos(k) == 0) { out.i0 = k; break; }
+  for (int64_t k = 0; k < m; ++k) {
+    int64_t s = pos(k);
+    out.bwt[(size_t)k] = s ? text[beg + s - 1] : 0;
+    if (s && k > out.i0) { int64_t u = m - s; out.gt_begin[(size_t)(u >> 5)] |= 1u << (u & 31); }
+  }
+  // bit u = 0: position end, [text[end..) > text[beg..)]
+  if (end < n && !gt_of_beg) out.gt_begin[0] |= 1u;
+}
+
+// number of suffixes of the half-block smaller than text[p..n): binary search with direct text
+// comparison (what em_compute_initial_ranks.hpp:222-319 computes for one position)
+static inline int64_t rank_by_search(const uint8_t *text, int64_t n, const HalfBlock &hb, int64_t p) {
+  if (p >= n) return 0;
+  auto less = [&](int64_t s) {  // text[s..) < text[p..) ?
+    int64_t k = 0;
+    while (s + k < n && p + k < n) {
+      uint8_t a = text[s + k], b = text[p + k];
+      if (a != b) return a < b;
+      ++k;
+    }
+    return s + k >= n;  // the shorter suffix is smaller (s != p)
+  };
+  int64_t lo = 0, hi = hb.size;
+  while (lo < hi) {
+    int64_t md = (lo + hi) / 2;
+    int64_t s = hb.beg + ((int64_t)hb.psa_lo[(size_t)md] | (hb.psa_hi.empty() ? 0 : (int64_t)hb.psa_hi[(size_t)md] << 32));
+    if (less(s)) lo = md + 1; else hi = md;
+  }
+  return lo;
+}
+
+}  // namespace psa_host

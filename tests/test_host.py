@@ -1,0 +1,179 @@
+"""Host side of the drop-in: the suffix sorter / start-rank search (CPU), the construct_sa command
+line (flag syntax, error behaviour of src/main.cpp:133-246 -- CPU), and construct_sa end to end
+against the reference's .sa5 hashes (GPU)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from golden import inputs as gin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "host")
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+CLI = os.path.join(HOST, "construct_sa")
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(HOST, "libpsascan_host.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", HOST, "libpsascan_host.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.psh_suffix_array.argtypes = [orc.u8p, C.c_int64, orc.i64p]
+    L.psh_sort_halfblock.argtypes = [orc.u8p, C.c_int64, C.c_int64, C.c_int64, orc.u8p,
+                                     np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), orc.u8p, C.POINTER(C.c_int64),
+                                     np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
+    L.psh_rank_by_search.argtypes = [orc.u8p, C.c_int64, C.c_int64, C.c_int64,
+                                     np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int64]
+    L.psh_rank_by_search.restype = C.c_int64
+    return L
+
+
+def texts():
+    rng = np.random.default_rng(17)
+    return {
+        "rand254": rng.integers(0, 254, 5000, dtype=np.uint8),
+        "sig4z": rng.integers(0, 4, 5000, dtype=np.uint8),
+        "sig2": rng.integers(97, 99, 4000, dtype=np.uint8),
+        "per3": np.frombuffer((b"abc" * 1400)[:4000], np.uint8).copy(),
+        "alla": np.full(3000, 97, np.uint8),
+        "fib": gin.fib()[:4181].copy(),
+        "zeros": np.zeros(2500, np.uint8),
+        "runs": np.repeat(rng.integers(0, 5, 300, dtype=np.uint8), rng.integers(1, 40, 300)),
+    }
+
+
+@pytest.mark.parametrize("name", list(texts().keys()))
+def test_sais_vs_oracle(H, name):
+    t = texts()[name]
+    sa = np.zeros(len(t), np.int64)
+    H.psh_suffix_array(t, len(t), sa)
+    assert np.array_equal(sa, orc.suffix_array(t))
+
+
+def test_sais_tiny(H):
+    for t in (b"a", b"ab", b"ba", b"aa", b"aab", b"baa", b"abab", b"\x00\x00", b"cab"):
+        a = orc.as_u8(t).copy()
+        sa = np.zeros(len(a), np.int64)
+        H.psh_suffix_array(a, len(a), sa)
+        assert np.array_equal(sa, orc.suffix_array(a)), t
+
+
+@pytest.mark.parametrize("name", list(texts().keys()))
+def test_sort_halfblock_vs_definition(H, name):
+    """Block in the middle of the text: order and gt_begin must follow the WHOLE-text suffix order."""
+    t = texts()[name]
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    for (b, e) in [(n // 5, n // 2), (0, n // 3), (n // 2, n), (n - 7, n), (3, 4), (n // 2, n // 2 + 2)]:
+        m = e - b
+        # gt_tail bit v = [text[e+v..) > text[e..)], v in [1, m]
+        gt_tail = orc.packbits([0] + [int(e + v < n and isa[e + v] > isa[e]) if e < n else 0 for v in range(1, m + 1)] + [0] * 8)
+        psa = np.zeros(m, np.uint32)
+        bwt = np.zeros(m, np.uint8)
+        gt = np.zeros((m + 31) // 32 + 1, np.uint32)
+        i0 = C.c_int64(-1)
+        assert H.psh_sort_halfblock(t, n, b, e, gt_tail, psa, bwt, C.byref(i0), gt) == 0
+        wpsa, wbwt, wi0, wgt = orc.partial_sa(t, sa, isa, b, e)
+        assert np.array_equal(psa.astype(np.int64), wpsa), (name, b, e)
+        assert np.array_equal(bwt, wbwt) and i0.value == wi0
+        assert np.array_equal(orc.bits(gt.view(np.uint8), m), orc.bits(wgt, m)), (name, b, e)
+        for p in (e, min(n, e + 5), n):
+            want = int((isa[b:e] < (isa[p] if p < n else -1)).sum())
+            assert H.psh_rank_by_search(t, n, b, m, psa, p) == want
+
+
+def test_sort_halfblock_rejects_byte_255(H):
+    t = np.array([1, 2, 255, 3, 4, 5], np.uint8)
+    z = np.zeros(8, np.uint8)
+    out = (np.zeros(4, np.uint32), np.zeros(4, np.uint8), np.zeros(2, np.uint32))
+    i0 = C.c_int64(0)
+    assert H.psh_sort_halfblock(t, 6, 0, 4, z, out[0], out[1], C.byref(i0), out[2]) == -1
+
+
+# ------------------------------------------------------------------ command line (no GPU needed for these paths)
+def cli(args, stdin=""):
+    if not os.path.exists(CLI):
+        pytest.skip("host/construct_sa not built")
+    return subprocess.run([CLI] + args, input=stdin, capture_output=True, text=True, timeout=600)
+
+
+def test_cli_help_exits_with_failure():
+    r = cli(["-h"])                                  # main.cpp:159-161 -- usage + EXIT_FAILURE
+    assert r.returncode == 1 and "Usage:" in r.stdout and "--mem=MEM" in r.stdout
+
+
+def test_cli_missing_file_and_bad_mem(tmp_path):
+    r = cli([])
+    assert r.returncode == 1 and "FILE not provided" in r.stderr
+    r = cli([str(tmp_path / "nope.txt")])
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    f = tmp_path / "t.txt"
+    f.write_bytes(b"banana")
+    for bad in ("12x", "k", "1kib", "5Xi"):
+        r = cli(["-m", bad, str(f)])
+        assert r.returncode == 1 and "parsing RAM limit" in r.stderr, bad
+    r = cli(["-m", "0", str(f)])
+    assert r.returncode == 1 and "invalid RAM limit" in r.stderr
+
+
+def test_cli_memory_error_matches_reference(tmp_path):
+    """BASELINE configs[0] as literally written (-m 256Ki) is rejected by the reference with
+    'not enough memory to start threads' (psascan.hpp:81-86); same here, and no output is left."""
+    f = tmp_path / "t.txt"
+    f.write_bytes(bytes(gin.rand1m()[:4096]))
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    r = subprocess.run([CLI, "-m", "256Ki", str(f)], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 1 and "not enough memory to start threads. You need at least 113MiB" in r.stderr
+    assert not os.path.exists(str(f) + ".sa5")
+
+
+def test_cli_overwrite_prompt(tmp_path):
+    f = tmp_path / "t.txt"
+    f.write_bytes(b"banana")
+    out = tmp_path / "t.txt.sa5"
+    out.write_bytes(b"old")
+    r = cli([str(f)], stdin="n\n")                   # main.cpp:216-238
+    assert r.returncode == 1 and "Overwrite? [y/n]" in r.stdout and out.read_bytes() == b"old"
+
+
+# ------------------------------------------------------------------ end to end on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(GOLD.keys() - {"_comment"}))
+def test_cli_end_to_end_vs_reference_hashes(tmp_path, name):
+    g = GOLD[name]
+    f = tmp_path / (name + ".bin")
+    f.write_bytes(bytes(gin.GENERATORS[name]()))
+    # -m and thread count that give the reference's block structure for this fixture
+    threads = {118803662: "8", 29402727: "2"}[g["ram_use"]]
+    env = dict(os.environ, OMP_NUM_THREADS=threads)
+    r = subprocess.run([CLI, "-m", str(g["ram_use"]), "-v", str(f)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Max block size = {g['max_block_size']}" in r.stderr
+    assert "speed:" in r.stderr and "elapsed time:" in r.stderr       # psascan.hpp:128-130
+    data = (tmp_path / (name + ".bin.sa5")).read_bytes()
+    assert len(data) == 5 * g["n"]
+    assert hashlib.sha256(data).hexdigest() == g["sa5_sha256"]
+    assert sorted(os.listdir(tmp_path)) == [name + ".bin", name + ".bin.sa5"]   # no temp files left
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,block", [(1, 4), (2, 4), (5, 2), (1000, 64), (4097, 1000), (30000, 30000), (30000, 7000)])
+def test_cli_small_shapes(tmp_path, n, block):
+    rng = np.random.default_rng(n + block)
+    t = rng.integers(0, 3, n, dtype=np.uint8)
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    for mem in ("1G", "40"):            # last block with / without a right half (ram/10 rule)
+        out = tmp_path / f"x_{mem}.sa5"
+        r = subprocess.run([CLI, "-m", mem, "--block-size", str(block), "--chains", "32", "-o", str(out), str(f)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
