@@ -144,8 +144,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        backend = os.environ.get("PSASCAN_DIST_BACKEND", "nccl")     # "gloo" + PSASCAN_SHARE_GPU=1: rehearsal on one GPU
+        if os.environ.get("PSASCAN_SHARE_GPU") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import numpy as np
     import psascan_amd
     from psascan_amd import api, extras
@@ -171,11 +177,13 @@ def main():
     Lh["psa_hi"] = Rh["psa_hi"] = None
 
     # tail range of this rank (64-aligned cut points so gt words do not straddle ranks)
-    cuts = [mid + ((rs * r // world) // 64) * 64 for r in range(world)] + [n]
+    from psascan_amd import distributed as D      # cut logic shared with the gloo tests
+    cuts = D.tail_cuts(mid, n, world)
     tb, te = cuts[rank], cuts[rank + 1]
-    out_cuts = [(n * r // world) // 4096 * 4096 for r in range(world)] + [n]
+    out_cuts = D.output_cuts(n, world)
     ob, oe = out_cuts[rank], out_cuts[rank + 1]
-    ctx = min(n - te, 1 << 16)           # right context for the start rank of this range
+    ctx = D.context_len(te, n)           # right context for the start rank of this range
+    gt_words = max(cuts[r + 1] - cuts[r] for r in range(world)) // 32 + 4
     gap_words = ls + 2
     if world > 1:
         gap_t = torch.zeros(gap_words, dtype=torch.int32, device="cuda")
@@ -208,7 +216,7 @@ def main():
         if world > 1:
             dist.all_reduce(gap_t)                       # sum of the per-range gap arrays (update.hpp:86-96 on all ranges)
             # gt bits of every range (the per-round gt exchange of the block schedule)
-            mine = torch.zeros(((rs // world) // 32) + 4, dtype=torch.int32, device="cuda")
+            mine = torch.zeros(gt_words, dtype=torch.int32, device="cuda")
             L.psg_d2d(C.c_void_p(mine.data_ptr()), C.c_void_p(gt_out.ptr), 4 * ((te - tb + 31) // 32))
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)

@@ -1,0 +1,111 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of psascan_amd.distributed.sharded_pass with the
+oracle standing in for the kernels (test-only injection), checking the sharding logic: range cuts,
+right contexts, the gap all-reduce, placement of the gathered gt bits and the output partition."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import orc
+    from psascan_amd import distributed as D
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    rng = np.random.default_rng(5)
+    for kind in ("sig4", "alla"):
+        n = 6000
+        t = rng.integers(0, 4, n, dtype=np.uint8) if kind == "sig4" else np.full(n, 97, np.uint8)
+        b, mid, e = 500, 2500, 5777                      # block [b,mid), tail [mid,e): pass A shape
+        sa = orc.suffix_array(t); isa = orc.inverse(sa)
+        psa, bwt, i0, _ = orc.partial_sa(t, sa, isa, b, mid)
+        m = mid - b
+        rk = orc.Rank(bwt)
+        def gt_bits(hi, lo):                              # gt wrt mid of positions (lo, hi], u = hi - j
+            return orc.packbits([(isa[hi - u] if hi - u < n else -1) > isa[mid] for u in range(hi - lo)] + [0] * 64)
+        def rank_at(p):
+            return int((isa[b:mid] < (isa[p] if p < n else -1)).sum())
+
+        class Ops:
+            device = "cpu"
+            def new_i32(self, k): return torch.zeros(int(k), dtype=torch.int32)
+        ops = Ops()
+        gap_t = torch.zeros(m + 2, dtype=torch.int32)
+        T = e - mid
+        words = (T // world + 64) // 32 + 4
+        def stream_fn(tb_r, te_r, ctx):
+            # the oracle is handed the exact start rank; the HIP path finds it inside the context
+            assert ctx % 64 == 0 and te_r + ctx <= e
+            g, gto, fin = orc.stream_pass(rk, i0, int(t[mid - 1]), t, tb_r, te_r, gt_bits(te_r, tb_r), rank_at(te_r))
+            gap_t[: m + 1] += torch.from_numpy(g.astype(np.int32))
+            out = torch.zeros(words, dtype=torch.int32)
+            raw = np.zeros(words * 4, np.uint8); raw[: len(gto)] = gto[: words * 4]
+            out[:] = torch.from_numpy(raw.view(np.int32))
+            return out
+        cuts, parts = D.sharded_pass(dist, ops, world, rank, mid, e, stream_fn, gap_t, words)
+        assert cuts[0] == mid and cuts[-1] == e and all(cuts[k] <= cuts[k + 1] for k in range(world))
+        want_gap, want_gt, _ = orc.stream_pass(rk, i0, int(t[mid - 1]), t, mid, e, gt_bits(e, mid), rank_at(e))
+        assert np.array_equal(gap_t[: m + 1].numpy().astype(np.uint64), want_gap), kind
+        bits = [orc.bits(p.numpy().view(np.uint8), cuts[r + 1] - cuts[r]) for r, p in enumerate(parts)]
+        got = D.assemble_gt(bits, cuts, e)
+        assert np.array_equal(got, orc.bits(want_gt, T)), kind
+        oc = D.output_cuts(n, world)
+        assert oc[0] == 0 and oc[-1] == n and all(oc[k] <= oc[k + 1] for k in range(world))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("WORKER_OK", rank)
+""")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pass_gloo(tmp_path, world):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-3000:]
+
+
+def test_cuts_properties():
+    from psascan_amd import distributed as D
+    for (tb, te, w) in [(0, 1000, 2), (5, 70, 4), (0, 63, 8), (100, 100, 3), (0, 1 << 31, 8), (7, 4097, 5)]:
+        c = D.tail_cuts(tb, te, w)
+        assert c[0] == tb and c[-1] == te and len(c) == w + 1
+        assert all(c[k] <= c[k + 1] for k in range(w))
+        assert all((te - c[k]) % 64 == 0 for k in range(1, w) if c[k] not in (tb, te))
+        for k in range(w):
+            ctx = D.context_len(c[k + 1], te)
+            assert ctx % 64 == 0 and c[k + 1] + ctx <= te
+    for n, w in [(5, 2), (4096, 2), (100000, 8), (1 << 32, 8)]:
+        oc = D.output_cuts(n, w)
+        assert oc[0] == 0 and oc[-1] == n and all(oc[k] <= oc[k + 1] for k in range(w))
+        assert all(x % 4096 == 0 or x == n for x in oc[:-1])
