@@ -86,6 +86,7 @@ typedef struct {
   int64_t rounds;          /* stream kernel launches                                */
   double kernel_ms;        /* time of the stream kernel launches (HIP events)       */
   double total_ms;         /* whole call                                            */
+  double hist_ms;          /* rank-log sort + histogram (0 when atomics are used)   */
 } psg_stream_stats;
 
 int psg_stream_gap(const psg_rank_t *rank, int64_t block_i0, int block_last_symbol,

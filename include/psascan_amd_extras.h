@@ -22,6 +22,9 @@ int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t e
  * adjacent pairs (k, k+1) that are NOT in suffix order.                                      */
 int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples,
                    uint64_t seed, int64_t *bad_pairs, uint64_t *sum);
+/* gap[v] += #{k : log[k] == v}, v in [0,m]; entries 0xFFFFFFFF are ignored; the log is clobbered.
+ * (the atomics-free gap update of psg_stream_gap, exposed for tests)                          */
+int psgx_gap_hist(uint32_t *d_log, int64_t nlog, int64_t m, uint32_t *d_gap);
 #ifdef __cplusplus
 }
 #endif

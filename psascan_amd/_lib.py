@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpsascan_hip.so")
+LIB_PATH = os.environ.get("PSASCAN_AMD_LIB") or os.path.join(HERE, "libpsascan_hip.so")
 
 
 class PsgError(RuntimeError):
@@ -14,7 +14,7 @@ class PsgError(RuntimeError):
 
 class StreamStatsC(C.Structure):
     _fields_ = [("n_chains", C.c_int64), ("chain_len", C.c_int64), ("warmup_steps", C.c_int64), ("unresolved", C.c_int64),
-                ("rounds", C.c_int64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("rounds", C.c_int64), ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("hist_ms", C.c_double)]
 
 
 class HbDescC(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
 EXTRA_SIGNATURES = {
     "psgx_gen_text": (_int, [_vp, _i64, _int, _int, C.c_uint64]),
     "psgx_sort_halfblock": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
+    "psgx_gap_hist": (_int, [_vp, _i64, _i64, _vp]),
     "psgx_check_sa5": (_int, [_vp, _i64, _vp, _i64, _i64, C.c_uint64, C.POINTER(_i64), C.POINTER(C.c_uint64)]),
 }
 

@@ -1,0 +1,241 @@
+// gap_hist.hip -- gap increments without random atomics (replaces update.hpp:86-96's one random
+// read-modify-write per streamed suffix; random u32 atomics top out at 17.9 G/s on MI355X,
+// profiles/r01_membench.txt).
+//
+// The stream kernel (MODE 2) logs the rank of every streamed suffix with coalesced stores.  Here
+// the log is partitioned so that every WINDOW of 2^WBITS consecutive gap counters becomes one
+// contiguous piece of it, and each window is histogrammed in LDS and added to the gap array with
+// coalesced read-modify-writes.  The partition is a hand-written two-level MSD radix split
+// (<= 512 bins per level) with deterministic offsets: persistent workgroups own private output
+// cursors, so there are no global atomics and no ordering requirements; tiles are staged in LDS
+// and written as per-bin runs.  (The reference does the same thing for cache locality on the CPU:
+// stream.hpp:160-232 buckets every buffer of ranks by value range before the updaters run.)
+#include "dev_common.hpp"
+
+#include <algorithm>
+
+using namespace psg;
+
+#define WBITS 14
+#define WSIZE (1 << WBITS)
+#define CAP (1 << 17)      // log entries per histogram work item
+#define PBINS 512          // bins per partition level
+#define PT 8192            // entries per partition tile (32 per thread)
+#define PAD 0xFFFFFFFFu
+
+struct Tile {              // LDS of one partition workgroup (~60 KiB -> 2 workgroups per CU)
+  u32 stage[PT];
+  u16 sbin[PT];
+  u32 h[PBINS];
+  u32 loff[PBINS];
+  u64 gbase[PBINS];
+  u64 cur[PBINS];
+  u32 scratch[8];
+};
+
+// scatter one tile [beg, end) (end - beg <= PT) of `keys` into `out` at the workgroup's cursors
+__device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, i64 end, int shift, u32 mask, u32 *out) {
+  u32 v[PT / PSG_WG];
+  u32 r[PT / PSG_WG];
+  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.h[b] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PT / PSG_WG; ++j) {
+    i64 k = beg + j * PSG_WG + threadIdx.x;
+    v[j] = k < end ? keys[k] : PAD;
+    if (v[j] != PAD) r[j] = atomicAdd(&S.h[(v[j] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  // exclusive scan over the 512 bins (2 per thread) + advance the cursors
+  u32 a = S.h[2 * threadIdx.x], b2 = S.h[2 * threadIdx.x + 1], tot;
+  u32 pre = block_excl_scan<u32>(a + b2, S.scratch, tot);
+  S.loff[2 * threadIdx.x] = pre;
+  S.loff[2 * threadIdx.x + 1] = pre + a;
+  S.gbase[2 * threadIdx.x] = S.cur[2 * threadIdx.x];
+  S.gbase[2 * threadIdx.x + 1] = S.cur[2 * threadIdx.x + 1];
+  S.cur[2 * threadIdx.x] += a;
+  S.cur[2 * threadIdx.x + 1] += b2;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PT / PSG_WG; ++j) {
+    if (v[j] != PAD) {
+      u32 bin = (v[j] >> shift) & mask;
+      u32 slot = S.loff[bin] + r[j];
+      S.stage[slot] = v[j];
+      S.sbin[slot] = (u16)bin;
+    }
+  }
+  __syncthreads();
+  for (u32 s = threadIdx.x; s < tot; s += PSG_WG) {
+    u32 bin = S.sbin[s];
+    out[S.gbase[bin] + (s - S.loff[bin])] = S.stage[s];
+  }
+  __syncthreads();
+}
+
+// level 1, step A: persistent workgroup g counts its tiles (g, g+G, ...)
+__global__ __launch_bounds__(PSG_WG) void part_count_kernel(const u32 *keys, i64 n, int shift, u32 *counts) {
+  __shared__ u32 h[PBINS];
+  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) h[b] = 0;
+  __syncthreads();
+  i64 ntiles = (n + PT - 1) / PT;
+  for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    i64 beg = tile * PT;
+    for (int j0 = 0; j0 < PT / PSG_WG; j0 += 8) {   // 8 independent loads in flight, then the LDS atomics
+      u32 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { i64 k = beg + (j0 + j) * PSG_WG + threadIdx.x; v[j] = k < n ? keys[k] : PAD; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] >> shift], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) counts[(i64)blockIdx.x * PBINS + b] = h[b];
+}
+
+// level 1, step B (one workgroup of 512 threads): off[g][b] = start of workgroup g's run inside bin b
+__global__ __launch_bounds__(PBINS) void part_offsets_kernel(const u32 *counts, int G, u64 *off, u64 *bin_base) {
+  __shared__ u64 tot[PBINS];
+  int b = threadIdx.x;
+  u64 t = 0;
+  for (int g = 0; g < G; ++g) t += counts[(i64)g * PBINS + b];
+  tot[b] = t;
+  __syncthreads();
+  if (b == 0) {  // 512-entry exclusive scan; tiny
+    u64 run = 0;
+    for (int k = 0; k < PBINS; ++k) { u64 x = tot[k]; tot[k] = run; run += x; }
+    bin_base[PBINS] = run;
+  }
+  __syncthreads();
+  u64 run = tot[b];
+  bin_base[b] = run;
+  for (int g = 0; g < G; ++g) { off[(i64)g * PBINS + b] = run; run += counts[(i64)g * PBINS + b]; }
+}
+
+// level 1, step C: persistent workgroup g scatters its tiles at its private cursors
+__global__ __launch_bounds__(PSG_WG) void part_scatter_kernel(const u32 *keys, i64 n, int shift, const u64 *off, u32 *out) {
+  __shared__ Tile S;
+  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.cur[b] = off[(i64)blockIdx.x * PBINS + b];
+  __syncthreads();
+  i64 ntiles = (n + PT - 1) / PT;
+  for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    scatter_tile(S, keys, tile * PT, std::min<i64>(tile * PT + PT, n), shift, 0xFFFFFFFFu, out);
+}
+
+// level 2: workgroup b splits segment b of level 1 by the next bits; records the window starts
+__global__ __launch_bounds__(PSG_WG) void part_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, u32 *out, u64 *win_off) {
+  __shared__ Tile S;
+  const i64 sb = (i64)bin_base[blockIdx.x], se = (i64)bin_base[blockIdx.x + 1];
+  const u32 mask = (1u << bits2) - 1u;
+  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.h[b] = 0;
+  __syncthreads();
+  for (i64 k0 = sb; k0 < se; k0 += 8 * PSG_WG) {
+    u32 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * PSG_WG + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.h[(v[j] >> WBITS) & mask], 1u);
+  }
+  __syncthreads();
+  u32 a = S.h[2 * threadIdx.x], b2 = S.h[2 * threadIdx.x + 1], tot;
+  u32 pre = block_excl_scan<u32>(a + b2, S.scratch, tot);
+  S.cur[2 * threadIdx.x] = (u64)sb + pre;
+  S.cur[2 * threadIdx.x + 1] = (u64)sb + pre + a;
+  __syncthreads();
+  for (u32 c = threadIdx.x; c <= mask; c += PSG_WG) win_off[((i64)blockIdx.x << bits2) + c] = S.cur[c];
+  __syncthreads();
+  for (i64 beg = sb; beg < se; beg += PT) scatter_tile(S, keys, beg, std::min<i64>(beg + PT, se), WBITS, mask, out);
+}
+
+__global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 nwin, u64 *cnt) {
+  i64 w = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (w >= nwin) return;
+  u64 c = off[w + 1] - off[w];
+  cnt[w] = (c + CAP - 1) / CAP;
+}
+
+// one work item = up to CAP log entries of one window: LDS histogram, coalesced add to the gap array
+__global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap) {
+  __shared__ u32 h[WSIZE];
+  __shared__ i64 s_w;
+  i64 item = blockIdx.x;
+  if (threadIdx.x == 0) {  // window of this item: last w with item_pref[w] <= item
+    i64 lo = 0, hi = nwin;
+    while (lo + 1 < hi) {
+      i64 md = (lo + hi) >> 1;
+      if ((i64)item_pref[md] <= item) lo = md; else hi = md;
+    }
+    s_w = lo;
+  }
+  for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) h[k] = 0;
+  __syncthreads();
+  i64 w = s_w;
+  i64 sub = item - (i64)item_pref[w];
+  i64 beg = (i64)off[w] + sub * CAP, end = std::min<i64>(beg + CAP, (i64)off[w + 1]);
+  bool single = (i64)(off[w + 1] - off[w]) <= CAP;
+  for (i64 k = beg + threadIdx.x; k < end; k += PSG_WG) atomicAdd(&h[keys[k] & (WSIZE - 1)], 1u);
+  __syncthreads();
+  i64 base = w << WBITS;
+  for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) {
+    u32 c = h[k];
+    i64 idx = base + k;
+    if (c && idx <= m) {
+      if (single) gap[idx] += c; else atomicAdd(&gap[idx], c);
+    }
+  }
+}
+
+int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) {
+  EventTimer tm;
+  tm.start();
+  const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18 for m < 2^32
+  int bits_total = 0;
+  while (((i64)1 << bits_total) < nwin) ++bits_total;
+  const int bits2 = bits_total > 9 ? bits_total - 9 : 0;   // level 2 only when there are > 512 windows
+  const int shift1 = WBITS + bits2;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, PT)));
+  DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot;
+  int rc;
+  const i64 nwin_slots = bits2 ? ((i64)PBINS << bits2) : PBINS;
+  if ((rc = part1.alloc(nlog * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
+      (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
+    return rc;
+  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
+  hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
+  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, off.as<u64>(), part1.as<u32>());
+  PSG_HIP(hipGetLastError());
+  const u32 *sorted = part1.as<u32>();
+  const u64 *woff = bin_base.as<u64>();
+  if (bits2) {
+    // the log buffer itself is free now: reuse it as the level-2 output
+    hipLaunchKernelGGL(part_level2_kernel, dim3(PBINS), dim3(PSG_WG), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, d_log, win_off.as<u64>());
+    PSG_HIP(hipMemcpyAsync(win_off.as<u64>() + nwin_slots, bin_base.as<u64>() + PBINS, 8, hipMemcpyDeviceToDevice, stream()));
+    PSG_HIP(hipGetLastError());
+    sorted = d_log;
+    woff = win_off.as<u64>();
+  }
+  hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, stream(), woff, nwin, cnt.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(cnt.as<u64>(), nwin, tot.as<u64>()))) return rc;
+  u64 items = 0;
+  PSG_HIP(hipMemcpyAsync(&items, tot.p, 8, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if (items > 0) {
+    hipLaunchKernelGGL(hist_items_kernel, dim3((unsigned)items), dim3(PSG_WG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap);
+    PSG_HIP(hipGetLastError());
+  }
+  tm.stop();
+  PSG_HIP(hipStreamSynchronize(stream()));
+  if (ms) *ms = tm.ms();
+  return 0;
+}
+
+// test entry (include/psascan_amd_extras.h): histogram an explicit rank log
+extern "C" int psgx_gap_hist(uint32_t *d_log, int64_t nlog, int64_t m, uint32_t *d_gap) {
+  PSG_REQUIRE(d_log && d_gap && nlog >= 0 && m >= 0 && m < 0xFFFFFFFFll, "psgx_gap_hist");
+  if (nlog == 0) return 0;
+  return psg::gap_hist_from_log(d_log, nlog, m, d_gap, nullptr);
+}

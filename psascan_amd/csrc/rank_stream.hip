@@ -13,10 +13,15 @@
 #include "dev_common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using namespace psg;
 
+#ifndef PSG_STREAM_MIN_WAVES
+#define PSG_STREAM_MIN_WAVES 1      // waves per SIMD requested from the register allocator (B <= 64 layouts)
+#endif
 #define SB_SHIFT 24                 // blocks per superblock = 2^24
 #define SEG_BLOCKS 64               // blocks per build segment (one workgroup)
 #define GROUP_SEGS 256              // segments per scan group
@@ -258,15 +263,16 @@ struct StreamParams {
   const u64 *g_tot;
   int nsb;
   int *ovf_flag;
+  u32 *log;           // MODE 2: rank log, entry (step within chain) * K + chain
+  i64 K;              // total number of chains (log row length)
 };
 
-__device__ __forceinline__ u32 byte_of(const uint4 &v, int bi) {
-  u32 w = (bi & 8) ? ((bi & 4) ? v.w : v.z) : ((bi & 4) ? v.y : v.x);
-  return (w >> ((bi & 3) * 8)) & 255u;
-}
-
-template <int CNT, int B, bool CHECK_OVF>
-__global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
+// MODE 0: atomicAdd on the gap counters; 1: same with u32 overflow detection;
+// MODE 2: no atomics -- the ranks are logged (coalesced: one dword per lane per step, 256 B per
+//         wave) and histogrammed afterwards (gap_hist.hip).
+template <int CNT, int B, int MODE>
+__global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
+  constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
   load_tables(lds, P.g_T1, P.g_tot, P.nsb);
   const u64 *T1 = lds, *tot = lds + P.nsb * 256;
@@ -276,41 +282,56 @@ __global__ __launch_bounds__(PSG_WG) void stream_kernel(RankView<CNT, B> R, Stre
   i64 u0 = P.ctx + k * P.L;
   i64 u1 = std::min<i64>(u0 + P.L, P.T);
   i64 i = P.init[k];
-  // text cursor: descending bytes starting at tail[T-1-u0]
+  // text cursor: descending bytes starting at tail[T-1-u0], consumed from a 128-bit shift
+  // register (no dynamically indexed registers: hipcc would spill those to scratch memory and
+  // put a scratch load + vmcnt(0) on the per-step critical path)
   uintptr_t addr = (uintptr_t)(P.tail + (P.T - 1 - u0));
   uintptr_t last_addr = (uintptr_t)(P.tail + (P.T - u1));  // address of the last byte this chain needs
   const uint4 *cp = (const uint4 *)(addr & ~(uintptr_t)15);
-  int bi = (int)(addr & 15);
+  int tcnt = (int)(addr & 15) + 1;                         // bytes left in the current chunk
   uint4 cur = *cp, nxt = cur;
   if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
+  u64 tlo = (u64)cur.x | ((u64)cur.y << 32), thi = (u64)cur.z | ((u64)cur.w << 32);
+  {
+    int sh = (16 - tcnt) * 8;                              // bring byte (tcnt-1) of the chunk to the top
+    if (sh >= 64) { thi = tlo << (sh - 64); tlo = 0; }
+    else if (sh > 0) { thi = (thi << sh) | (tlo >> (64 - sh)); tlo <<= sh; }
+  }
   i64 w = u0 >> 5;
   bool ovf = false;
+  u32 gin = P.gt_in ? P.gt_in[w] : 0u;
   for (i64 u = u0; u < u1; u += 32, ++w) {
-    u32 gin = P.gt_in ? P.gt_in[w] : 0u;
+    u32 gin_next = (P.gt_in && u + 32 < u1) ? P.gt_in[w + 1] : 0u;   // prefetch the next gt word
     u32 gout = 0;
     int steps = (int)std::min<i64>(32, u1 - u);
     for (int t = 0; t < steps; ++t) {
-      u32 c = byte_of(cur, bi);
+      u32 c = (u32)(thi >> 56);
+      thi = (thi << 8) | (tlo >> 56);
+      tlo <<= 8;
       bool gt_i0 = i > P.i0;
       gout |= (u32)gt_i0 << t;
       i64 ni = lf_core<CNT, B>(R, T1, tot, i, c);
       ni -= (gt_i0 && c == 0) ? 1 : 0;
       ni += (c == P.last && ((gin >> t) & 1u)) ? 1 : 0;
       i = ni;
-      if (CHECK_OVF) {
+      if (MODE == 2) {
+        P.log[(u - u0 + t) * P.K + k] = (u32)i;
+      } else if (CHECK_OVF) {
         u32 old = atomicAdd(&P.gap[i], 1u);
         ovf |= (old == 0xFFFFFFFFu);
       } else {
         atomicAdd(&P.gap[i], 1u);
       }
-      if (--bi < 0) {
-        bi = 15;
-        cur = nxt;
+      if (--tcnt == 0) {
+        tcnt = 16;
+        tlo = (u64)nxt.x | ((u64)nxt.y << 32);
+        thi = (u64)nxt.z | ((u64)nxt.w << 32);
         --cp;
         if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
       }
     }
     if (P.gt_out) P.gt_out[w - (P.ctx >> 5)] = gout;
+    gin = gin_next;
   }
   P.fin[k] = i;
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
@@ -499,12 +520,22 @@ template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams 
   size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
   hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
 }
-template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, bool check_ovf) {
+template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode) {
   RankView<CNT, B> R{r->d_blocks, r->m};
   size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
   dim3 grid((unsigned)cdiv(P.nchains, PSG_WG));
-  if (check_ovf) hipLaunchKernelGGL((stream_kernel<CNT, B, true>), grid, dim3(PSG_WG), lds, stream(), R, P);
-  else hipLaunchKernelGGL((stream_kernel<CNT, B, false>), grid, dim3(PSG_WG), lds, stream(), R, P);
+  if (mode == 2) hipLaunchKernelGGL((stream_kernel<CNT, B, 2>), grid, dim3(PSG_WG), lds, stream(), R, P);
+  else if (mode == 1) hipLaunchKernelGGL((stream_kernel<CNT, B, 1>), grid, dim3(PSG_WG), lds, stream(), R, P);
+  else hipLaunchKernelGGL((stream_kernel<CNT, B, 0>), grid, dim3(PSG_WG), lds, stream(), R, P);
+}
+
+// resident workgroups per CU of the stream kernel that will be launched (occupancy API)
+template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int *blocks) {
+  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  *blocks = 0;
+  if (mode == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 2>, PSG_WG, lds);
+  else if (mode == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 1>, PSG_WG, lds);
+  else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 0>, PSG_WG, lds);
 }
 
 extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
@@ -531,8 +562,26 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
   for (int c = 0; c < 256; ++c) { i64 t = r->count[c] + (c == last_sym) - (c == 0); C[c] = s; s += t; }
   DevBuf T1, tot;
   if (int rc = make_tables(r, C, T1, tot)) return rc;
-  // chain plan
-  i64 Ktarget = max_chains > 0 ? max_chains : (i64)256 * 32 * 64;
+  // gap update mode: log + histogram needs ranks that fit u32 and enough work to pay for the sort
+  int mode = T >= 0xFFFFFFFFll ? 1 : 0;
+  {
+    const char *e = getenv("PSG_GAP_MODE");   // "atomic" | "log" | unset = auto
+    bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
+    if (e && !strcmp(e, "atomic")) want_log = false;
+    if (want_log && r->m < 0xFFFFFFFFll && mode == 0) mode = 2;
+  }
+  // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
+  // pass time: every chain has the same length)
+  i64 Ktarget = max_chains;
+  if (Ktarget <= 0) {
+    int blocks = 0, dev = 0, cus = 256;
+    DISPATCH_LAYOUT(r, query_occupancy, r, mode, &blocks);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (blocks < 1) blocks = 4;
+    if (blocks > 8) blocks = 8;
+    Ktarget = (i64)blocks * cus * PSG_WG;
+  }
   i64 L = cdiv(cdiv(T, Ktarget), 64) * 64;
   i64 K = cdiv(T, L);
   st.n_chains = K; st.chain_len = L;
@@ -564,8 +613,12 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
   }
   st.unresolved = nun;
   if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
-  bool check_ovf = T >= 0xFFFFFFFFll;
-  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>()};
+  DevBuf log_d;
+  if (mode == 2) {
+    if ((rc = log_d.alloc(K * L * 4))) return rc;
+    PSG_HIP(hipMemsetAsync(log_d.p, 0xFF, (size_t)(K * L * 4), stream()));   // 0xFFFFFFFF = no entry
+  }
+  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K};
   double kms = 0;
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
@@ -588,7 +641,7 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
       SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
     }
     ktm.start();
-    DISPATCH_LAYOUT(r, launch_stream, r, SP, check_ovf);
+    DISPATCH_LAYOUT(r, launch_stream, r, SP, mode);
     ktm.stop();
     PSG_HIP(hipGetLastError());
     PSG_HIP(hipMemcpyAsync(fin.data(), fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
@@ -605,6 +658,12 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
       return PSG_ECHECK;
     }
   if (ctx == 0 && lo[0] != rank_at_end) { set_error("stream: chain 0 did not start at rank_at_tail_end"); return PSG_ECHECK; }
+  double hist_ms = 0;
+  if (mode == 2) {
+    if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms))) return rc;
+    log_d.alloc(16);   // give the log back to the pool before returning
+  }
+  st.hist_ms = hist_ms;
   int ovf = 0;
   PSG_HIP(hipMemcpyAsync(&ovf, flag_d.p, 4, hipMemcpyDeviceToHost, stream()));
   total_tm.stop();

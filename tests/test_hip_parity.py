@@ -118,6 +118,49 @@ def test_stream_gap_mid_tail_and_accumulate(A):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+@pytest.mark.parametrize("kind", ["rand255", "sig4z", "alla", "fib"])
+def test_stream_gap_log_mode(A, kind, monkeypatch):
+    """gap increments through the rank log + sorted-window histogram instead of atomics (gap_hist.hip),
+    incl. skewed inputs where a single gap slot receives almost everything."""
+    monkeypatch.setenv("PSG_GAP_MODE", "log")
+    n = 200000 if kind in ("rand255", "sig4z") else 60000
+    t = make_text(kind, n, 21)
+    b, e = 1000, 1000 + n // 3
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m = e - b
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    T = n - e
+    d_gap = A.upload(np.full(m + 1, 3, np.uint32))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300)
+    assert fin == want_fin and st.hist_ms > 0
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap + 3)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
+@pytest.mark.parametrize("m,nlog,skew", [(100, 5000, 0), (66666, 133504, 0), (70000, 300, 0), (1 << 20, 1 << 22, 0),
+                                         (9_000_000, 3_000_000, 0), (20_000_000, 6_000_000, 1), (5000, 2_000_000, 2)])
+def test_gap_hist_from_log(A, gpu_lib, m, nlog, skew):
+    """hand-written two-level partition + LDS window histograms vs numpy bincount
+    (one level when <= 512 windows, two levels above; skewed logs: hot windows / one hot counter)."""
+    from psascan_amd._lib import check
+    rng = np.random.default_rng(m + nlog)
+    if skew == 0:
+        v = rng.integers(0, m + 1, nlog).astype(np.uint32)
+    elif skew == 1:
+        v = np.where(rng.random(nlog) < 0.7, rng.integers(12_345_000, 12_345_900, nlog), rng.integers(0, m + 1, nlog)).astype(np.uint32)
+    else:
+        v = np.where(rng.random(nlog) < 0.95, 4321, rng.integers(0, m + 1, nlog)).astype(np.uint32)
+    v[rng.integers(0, nlog, nlog // 50)] = 0xFFFFFFFF
+    d_log = A.upload(v)
+    d_gap = A.upload(np.full(m + 1, 2, np.uint32))
+    check(gpu_lib.psgx_gap_hist(d_log.ptr, nlog, m, d_gap.ptr))
+    want = np.bincount(v[v != 0xFFFFFFFF], minlength=m + 1).astype(np.uint32) + 2
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1), want)
+
+
 def test_stream_gap_empty_tail(A):
     bwt = np.array([0, 1, 2, 1], np.uint8)
     r = A.rank_build(A.upload(bwt, pad_to=16), 4)

@@ -46,6 +46,24 @@ __global__ __launch_bounds__(256) void chase_kernel(const uint4 *tab, size_t nro
   if (acc == 0x12345678) *sink = acc;
 }
 
+// the real per-step load shape of stream_kernel<256,64>: one dword from the counter sector + NX
+// dwordx4 loads that all fall into ONE other 64-byte sector of the same 1088-byte row
+template <int NX>
+__global__ __launch_bounds__(256) void shape_kernel(const uint4 *tab, size_t nrows, int steps, uint32_t *sink) {
+  uint64_t s = mix((uint64_t)blockIdx.x * 256 + threadIdx.x);
+  uint32_t acc = 0;
+  for (int t = 0; t < steps; ++t) {
+    uint64_t r = s % nrows;
+    const uint4 *row = tab + r * 68;
+    uint32_t x = ((const uint32_t *)row)[(s >> 40) & 255];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { uint4 w = row[64 + q]; x ^= w.x + w.y + w.z + w.w; }
+    acc += x;
+    s = mix(s ^ x);
+  }
+  if (acc == 0x12345678) *sink = acc;
+}
+
 template <int U>
 __global__ __launch_bounds__(256) void atomic_kernel(uint32_t *cnt, size_t ncnt, int steps) {
   uint64_t s = mix((uint64_t)blockIdx.x * 256 + threadIdx.x);
@@ -88,6 +106,12 @@ int main(int argc, char **argv) {
   printf("1 load + 1 atomic / step  : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
   ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, true, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
   printf("2 loads + 1 atomic / step : %8.2f G steps/s   <- stream kernel shape\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<1>), dim3(grid), dim3(256), 0, 0, tab, nrows, steps, sink); });
+  printf("dword + 1 x dwordx4 / step: %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<2>), dim3(grid), dim3(256), 0, 0, tab, nrows, steps, sink); });
+  printf("dword + 2 x dwordx4 / step: %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((shape_kernel<4>), dim3(grid), dim3(256), 0, 0, tab, nrows, steps, sink); });
+  printf("dword + 4 x dwordx4 / step: %8.2f G steps/s   <- stream_kernel<256,64> loads\n", lanes * steps / ms / 1e6);
   // half the lanes (4 waves/SIMD) to see the latency/occupancy dependence
   ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, true, 68>), dim3(grid / 2), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
   printf("  same at 4 waves/SIMD    : %8.2f G steps/s\n", lanes / 2 * steps / ms / 1e6);
