@@ -68,10 +68,59 @@ template <int B> __device__ __forceinline__ u32 count_prefix(const u8 *data, u32
   return acc;
 }
 
+// bytes equal to c among bytes [lo, hi) of an NCH*16-byte region (lo, hi relative to it)
+template <int NCH> __device__ __forceinline__ u32 count_range(const u8 *data, u32 c, int lo, int hi) {
+  const uint4 *p = (const uint4 *)data;
+  u32 c4 = c * 0x01010101u;
+  u32 acc = 0;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    uint4 v = p[q];
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int o = q * 16 + k * 4;
+      int rh = hi - o, rl = lo - o;
+      u32 kh = rh >= 4 ? 0x80808080u : (rh <= 0 ? 0u : (0x80808080u >> (32 - 8 * rh)));
+      u32 kl = rl >= 4 ? 0x80808080u : (rl <= 0 ? 0u : (0x80808080u >> (32 - 8 * rl)));
+      acc += __popc(swar_eq_mask(w[k], c4) & kh & ~kl);
+    }
+  }
+  return acc;
+}
+
+// The block counter holds the count at the block's MIDPOINT (not its start): a query then only
+// needs the half of the data area that lies between the midpoint and i -- at most MID bytes, i.e.
+// 2 dwordx4 loads for B = 64 instead of 4.  Measured on MI355X (tools/membench): a step of
+// 1 dword + 2 dwordx4 dependent random loads runs at 25 G steps/s, 1 dword + 4 dwordx4 (same two
+// sectors!) only at 15.7 G steps/s -- the load count per step, not the sector count, was the limit.
+// full-block count (first `off` bytes) and first-part count (first min(off, MID) bytes) in one pass
+template <int B, int MID> __device__ __forceinline__ u32 count_two(const u8 *data, u32 c, int off, u32 &first) {
+  const uint4 *p = (const uint4 *)data;
+  u32 c4 = c * 0x01010101u;
+  u32 acc = 0, accf = 0;
+#pragma unroll
+  for (int q = 0; q < B / 16; ++q) {
+    uint4 v = p[q];
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int rem = off - (q * 16 + k * 4);
+      u32 keep = rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u >> (32 - 8 * rem)));
+      u32 n = __popc(swar_eq_mask(w[k], c4) & keep);
+      acc += n;
+      if (q * 16 + k * 4 < MID) accf += n;   // compile-time condition (MID is a multiple of 4)
+    }
+  }
+  first = accf;
+  return acc;
+}
+
 template <int CNT, int B> struct RankView {
   const u8 *blocks;
   i64 m;
   static constexpr int STRIDE = 4 * CNT + B;
+  static constexpr int MID = B == 48 ? 32 : B / 2;   // multiple of 16, >= B - MID
 };
 
 // One LF step: returns C[c] + rank(i, c) (before the delta / gt corrections).
@@ -87,11 +136,16 @@ __device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1,
   i64 blk = i / B;
   int off = (int)(i - blk * B);
   const u8 *p = R.blocks + blk * (i64)RankView<CNT, B>::STRIDE;
+  constexpr int MID = RankView<CNT, B>::MID;
   u32 ctr = *(const u32 *)(p + 4 * code);
-  u32 hit = count_prefix<B>(p + 4 * CNT, c, off);
+  bool upper = off >= MID;
+  i64 valid = R.m - blk * B;                       // symbols stored in this block (last block may be short)
+  int lim = valid < MID ? (int)valid : MID;
+  int lo = upper ? 0 : off, hi = upper ? off - MID : lim;
+  u32 cnt = count_range<MID / 16>(p + 4 * CNT + (upper ? MID : 0), c, lo, hi);
   i64 sb = blk >> SB_SHIFT;
   i64 base = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
-  return base + ctr + hit;
+  return base + ctr + (upper ? (i64)cnt : -(i64)cnt);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -171,7 +225,9 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
   constexpr int SEGSYM = SEG_BLOCKS * B;
   constexpr int STRIDE = 4 * CNT + B;
   __shared__ __attribute__((aligned(16))) u8 sym[SEGSYM];
+  constexpr int MID = RankView<CNT, B>::MID;
   __shared__ u16 cnt16[SEG_BLOCKS * CNT];
+  __shared__ u8 half8[SEG_BLOCKS * CNT];     // occurrences in the first MID bytes of the block
   __shared__ u8 code2sym[CNT];
   i64 seg = blockIdx.x;
   i64 base = seg * SEGSYM;
@@ -189,7 +245,9 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
     int blk = q / CNT, cd = q % CNT;
     i64 valid = m - (base + (i64)blk * B);
     int off = valid >= B ? B : (valid <= 0 ? 0 : (int)valid);
-    cnt16[q] = (u16)count_prefix<B>(sym + blk * B, code2sym[cd], off);
+    u32 first;
+    cnt16[q] = (u16)count_two<B, MID>(sym + blk * B, code2sym[cd], off, first);
+    half8[q] = (u8)first;
   }
   __syncthreads();
   // step 2: exclusive prefix over the 64 blocks, per code
@@ -212,7 +270,7 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
     if (gb >= nblk) continue;
     u64 abs0 = group_base[g * CNT + cd] + seg_pref[seg * CNT + cd];
     u64 sbb = group_base[sb_group * CNT + cd];
-    *(u32 *)(blocks + gb * STRIDE + 4 * cd) = (u32)(abs0 - sbb) + cnt16[q];
+    *(u32 *)(blocks + gb * STRIDE + 4 * cd) = (u32)(abs0 - sbb) + cnt16[q] + half8[q];   // count at the block midpoint
   }
   // step 4: data bytes
   for (int k = threadIdx.x; k < SEGSYM / 4; k += PSG_WG) {
@@ -274,6 +332,7 @@ template <int CNT, int B, int MODE>
 __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
   constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
+  __shared__ u32 lstage[MODE == 2 ? 4 * PSG_WG : 1];
   load_tables(lds, P.g_T1, P.g_tot, P.nsb);
   const u64 *T1 = lds, *tot = lds + P.nsb * 256;
   i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
@@ -315,7 +374,13 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
       ni += (c == P.last && ((gin >> t) & 1u)) ? 1 : 0;
       i = ni;
       if (MODE == 2) {
-        P.log[(u - u0 + t) * P.K + k] = (u32)i;
+        // 4 consecutive ranks of a chain leave as ONE dwordx4 store (memory instructions per step are
+        // the scarce resource of this kernel); lane-private LDS slots, no barrier needed
+        lstage[(t & 3) * PSG_WG + threadIdx.x] = (u32)i;
+        if ((t & 3) == 3) {
+          uint4 q4 = make_uint4(lstage[threadIdx.x], lstage[PSG_WG + threadIdx.x], lstage[2 * PSG_WG + threadIdx.x], lstage[3 * PSG_WG + threadIdx.x]);
+          ((uint4 *)P.log)[((u - u0 + t) >> 2) * P.K + k] = q4;
+        }
       } else if (CHECK_OVF) {
         u32 old = atomicAdd(&P.gap[i], 1u);
         ovf |= (old == 0xFFFFFFFFu);
@@ -332,6 +397,12 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
     }
     if (P.gt_out) P.gt_out[w - (P.ctx >> 5)] = gout;
     gin = gin_next;
+    if (MODE == 2 && (steps & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
+      int full = steps & ~3;
+      uint4 q4 = make_uint4(lstage[threadIdx.x], (steps & 3) > 1 ? lstage[PSG_WG + threadIdx.x] : 0xFFFFFFFFu,
+                            (steps & 3) > 2 ? lstage[2 * PSG_WG + threadIdx.x] : 0xFFFFFFFFu, 0xFFFFFFFFu);
+      ((uint4 *)P.log)[((u - u0 + full) >> 2) * P.K + k] = q4;
+    }
   }
   P.fin[k] = i;
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
@@ -447,7 +518,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   r->blocks_bytes = r->nblk * (i64)r->stride;
   int rc = 0;
   DevBuf code_d, seg_cnt, group_sum;
-  hipError_t e = psg::pool_alloc((void **)&r->d_blocks, (size_t)r->blocks_bytes);
+  hipError_t e = psg::pool_alloc((void **)&r->d_blocks, (size_t)r->blocks_bytes + 64);   // +64: the upper-part read of the last block may run 16 B over
   if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
   PSG_HIP(hipMemcpyAsync(code_d.p, r->code, 256, hipMemcpyHostToDevice, stream()));
