@@ -57,21 +57,54 @@ __device__ __forceinline__ void clear_bit(u32 *bv, i64 pos) { atomicAnd(&bv[pos 
 // =======================================================================================
 // K3: gap -> bitvector
 // =======================================================================================
+// Zero bits of one tile are (almost always) confined to a few hundred consecutive words: they are
+// collected in an LDS bitmap window and merged into the ones-filled output with one atomicAnd per
+// touched WORD (coalesced) instead of one per bit; bits beyond the window fall back to clear_bit.
+#define BMW 512   // words in the LDS bitmap window (16384 bits)
+
+struct BitWindow {
+  u32 w[BMW];
+  i64 base_word;
+};
+
+__device__ __forceinline__ void bw_init(BitWindow &W, i64 first_pos) {
+  for (int k = threadIdx.x; k < BMW; k += PSG_WG) W.w[k] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) W.base_word = first_pos >> 5;
+}
+__device__ __forceinline__ void bw_clear(BitWindow &W, u32 *bv, i64 pos) {
+  i64 k = (pos >> 5) - W.base_word;
+  if (k >= 0 && k < BMW) atomicAnd(&W.w[k], ~(1u << (pos & 31)));
+  else clear_bit(bv, pos);
+}
+__device__ __forceinline__ void bw_flush(BitWindow &W, u32 *bv) {
+  for (int k = threadIdx.x; k < BMW; k += PSG_WG) {
+    u32 x = W.w[k];
+    if (x != 0xFFFFFFFFu) atomicAnd(&bv[W.base_word + k], x);
+  }
+}
+
 __global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap, i64 m, const u64 *tile_pref, u32 *bv) {
   __shared__ u64 scratch[8];
+  __shared__ BitWindow W;
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u32 g[8];
   u64 s = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) { g[q] = base + q <= m ? gap[base + q] : 0; s += g[q]; }
   u64 tot;
-  u64 pre = tile_pref[blockIdx.x] + block_excl_scan<u64>(s, scratch, tot);
+  u64 tp = tile_pref[blockIdx.x];
+  u64 pre = tp + block_excl_scan<u64>(s, scratch, tot);
+  // first zero position of the tile: element j0 = blockIdx*TILE_V sits at j0 + tp + gap[j0]
+  bw_init(W, (i64)blockIdx.x * TILE_V + (i64)tp + (i64)gap[(i64)blockIdx.x * TILE_V]);
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     pre += g[q];
     i64 j = base + q;
-    if (j < m) clear_bit(bv, j + (i64)pre);
+    if (j < m) bw_clear(W, bv, j + (i64)pre);
   }
+  __syncthreads();
+  bw_flush(W, bv);
 }
 
 extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *d_bv, int64_t cap_bits, int64_t *nbits) {
@@ -195,6 +228,7 @@ __global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, co
 __global__ __launch_bounds__(PSG_WG) void split_apply_kernel(const u32 *gap, const u32 *bv, i64 block, const u64 *tile_g,
                                                                const u64 *tile_o, u32 *mbv_left, u32 *mbv_right) {
   __shared__ u64 scratch[8];
+  __shared__ BitWindow WL, WR;
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u32 g[8];
   u64 s = 0;
@@ -203,14 +237,23 @@ __global__ __launch_bounds__(PSG_WG) void split_apply_kernel(const u32 *gap, con
   int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
   u32 bits = n > 0 ? get_bits(bv, base, n, (block + 31) >> 5) : 0;
   u64 t0, t1;
-  u64 ps = tile_g[blockIdx.x] + block_excl_scan<u64>(s, scratch, t0);
-  u64 r1 = tile_o[blockIdx.x] + block_excl_scan<u64>((u64)__popc(bits), scratch, t1);
+  u64 tg = tile_g[blockIdx.x], to = tile_o[blockIdx.x];
+  u64 ps = tg + block_excl_scan<u64>(s, scratch, t0);
+  u64 r1 = to + block_excl_scan<u64>((u64)__popc(bits), scratch, t1);
+  // windows start at the tile's first possible positions: k0 + PS (left), r1 + PS (right)
+  i64 k0 = (i64)blockIdx.x * TILE_V;
+  bw_init(WL, k0 + (i64)tg);
+  bw_init(WR, (i64)to + (i64)tg);
+  __syncthreads();
   for (int q = 0; q < n; ++q) {
     ps += g[q];
     i64 k = base + q;
-    if ((bits >> q) & 1u) { clear_bit(mbv_right, (i64)(r1 + ps)); ++r1; }
-    else clear_bit(mbv_left, k + (i64)ps);
+    if ((bits >> q) & 1u) { bw_clear(WR, mbv_right, (i64)(r1 + ps)); ++r1; }
+    else bw_clear(WL, mbv_left, k + (i64)ps);
   }
+  __syncthreads();
+  bw_flush(WL, mbv_left);
+  bw_flush(WR, mbv_right);
 }
 
 extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_t ml, int64_t mr, int64_t tail_len,

@@ -219,60 +219,58 @@ __global__ __launch_bounds__(PSG_WG) void group_scan_kernel(u64 *group_sum, i64 
   }
 }
 
+// One workgroup per segment of 64 blocks.  Per-(block, code) occurrence counts are built with LDS
+// atomics -- one per symbol, instead of every code scanning every byte -- in two passes of 32
+// blocks; each u32 holds the count of the block's first part (< MID, low half) and of the rest
+// (high half), so the midpoint counter and the running prefix come out of one array.
 template <int CNT, int B>
 __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m, const u8 *code_g, const u32 *seg_pref,
                                                              const u64 *group_base, u8 *blocks, i64 nblk) {
   constexpr int SEGSYM = SEG_BLOCKS * B;
   constexpr int STRIDE = 4 * CNT + B;
-  __shared__ __attribute__((aligned(16))) u8 sym[SEGSYM];
   constexpr int MID = RankView<CNT, B>::MID;
-  __shared__ u16 cnt16[SEG_BLOCKS * CNT];
-  __shared__ u8 half8[SEG_BLOCKS * CNT];     // occurrences in the first MID bytes of the block
-  __shared__ u8 code2sym[CNT];
-  i64 seg = blockIdx.x;
-  i64 base = seg * SEGSYM;
-  if (CNT == 256) code2sym[threadIdx.x % CNT] = (u8)threadIdx.x;   // identity code
-  else {
-    if (threadIdx.x < CNT) code2sym[threadIdx.x] = 0;             // unused code slots
+  constexpr int HB = SEG_BLOCKS / 2;
+  __shared__ __attribute__((aligned(16))) u8 sym[SEGSYM];
+  __shared__ u32 cnt[HB * CNT];
+  __shared__ u8 code[256];
+  const i64 seg = blockIdx.x;
+  const i64 base = seg * SEGSYM;
+  code[threadIdx.x] = code_g[threadIdx.x];
+  if (base + SEGSYM <= m && ((uintptr_t)bwt & 15) == 0) {
+    for (int k = threadIdx.x; k < SEGSYM / 16; k += PSG_WG) ((uint4 *)sym)[k] = ((const uint4 *)(bwt + base))[k];
+  } else {
+    for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) sym[k] = base + k < m ? bwt[base + k] : 0;
+  }
+  // running count (relative to the superblock) at the start of the segment, for the code of this thread
+  const i64 g = seg / GROUP_SEGS;
+  const i64 sb = (seg * SEG_BLOCKS) >> SB_SHIFT;
+  const i64 sb_group = (sb << SB_SHIFT) / SEG_BLOCKS / GROUP_SEGS;
+  u32 run = 0;
+  if (threadIdx.x < CNT) run = (u32)(group_base[g * CNT + threadIdx.x] + seg_pref[seg * CNT + threadIdx.x] - group_base[sb_group * CNT + threadIdx.x]);
+  for (int half = 0; half < 2; ++half) {
+    for (int k = threadIdx.x; k < HB * CNT; k += PSG_WG) cnt[k] = 0;
     __syncthreads();
-    u32 cd = code_g[threadIdx.x];
-    if (cd != 0xFFu && cd < CNT) code2sym[cd] = (u8)threadIdx.x;
-  }
-  for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) sym[k] = base + k < m ? bwt[base + k] : 0;
-  __syncthreads();
-  // step 1: per (block, code) counts
-  for (int q = threadIdx.x; q < SEG_BLOCKS * CNT; q += PSG_WG) {
-    int blk = q / CNT, cd = q % CNT;
-    i64 valid = m - (base + (i64)blk * B);
-    int off = valid >= B ? B : (valid <= 0 ? 0 : (int)valid);
-    u32 first;
-    cnt16[q] = (u16)count_two<B, MID>(sym + blk * B, code2sym[cd], off, first);
-    half8[q] = (u8)first;
-  }
-  __syncthreads();
-  // step 2: exclusive prefix over the 64 blocks, per code
-  for (int cd = threadIdx.x; cd < CNT; cd += PSG_WG) {
-    u32 run = 0;
-    for (int blk = 0; blk < SEG_BLOCKS; ++blk) {
-      u32 v = cnt16[blk * CNT + cd];
-      cnt16[blk * CNT + cd] = (u16)run;
-      run += v;
+    for (int p = half * HB * B + threadIdx.x; p < (half + 1) * HB * B; p += PSG_WG) {
+      if (base + p < m) {
+        u32 cd = code[sym[p]];
+        if (cd != 0xFFu || CNT == 256) {
+          int blk = p / B, off = p - blk * B;
+          atomicAdd(&cnt[(blk - half * HB) * CNT + cd], off < MID ? 1u : 0x10000u);
+        }
+      }
     }
+    __syncthreads();
+    if (threadIdx.x < CNT) {
+      for (int blk = 0; blk < HB; ++blk) {
+        u32 v = cnt[blk * CNT + threadIdx.x];
+        i64 gb = seg * SEG_BLOCKS + half * HB + blk;
+        if (gb < nblk) *(u32 *)(blocks + gb * STRIDE + 4 * threadIdx.x) = run + (v & 0xFFFFu);   // count at the block midpoint
+        run += (v & 0xFFFFu) + (v >> 16);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // step 3: counters relative to the superblock base
-  i64 g = seg / GROUP_SEGS;
-  i64 sb = (seg * SEG_BLOCKS) >> SB_SHIFT;
-  i64 sb_group = (sb << SB_SHIFT) / SEG_BLOCKS / GROUP_SEGS;  // group index where the superblock starts
-  for (int q = threadIdx.x; q < SEG_BLOCKS * CNT; q += PSG_WG) {
-    int blk = q / CNT, cd = q % CNT;
-    i64 gb = seg * SEG_BLOCKS + blk;
-    if (gb >= nblk) continue;
-    u64 abs0 = group_base[g * CNT + cd] + seg_pref[seg * CNT + cd];
-    u64 sbb = group_base[sb_group * CNT + cd];
-    *(u32 *)(blocks + gb * STRIDE + 4 * cd) = (u32)(abs0 - sbb) + cnt16[q] + half8[q];   // count at the block midpoint
-  }
-  // step 4: data bytes
+  // data bytes
   for (int k = threadIdx.x; k < SEGSYM / 4; k += PSG_WG) {
     int blk = (k * 4) / B, o = (k * 4) % B;
     i64 gb = seg * SEG_BLOCKS + blk;
