@@ -40,6 +40,7 @@ void note_kernel_ms(double ms);
 hipError_t pool_alloc(void **p, size_t bytes);
 void pool_free(void *p);
 void pool_trim();
+size_t pool_cached_bytes();   // bytes held in the cache (reusable without asking the driver)
 
 // RAII device buffer for temporaries
 struct DevBuf {

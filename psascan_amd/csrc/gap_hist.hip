@@ -23,9 +23,8 @@ using namespace psg;
 #define PT 8192            // entries per partition tile (32 per thread)
 #define PAD 0xFFFFFFFFu
 
-struct Tile {              // LDS of one partition workgroup (~60 KiB -> 2 workgroups per CU)
+struct Tile {              // LDS of one partition workgroup (~44 KiB -> 3 workgroups per CU)
   u32 stage[PT];
-  u16 sbin[PT];
   u32 h[PBINS];
   u32 loff[PBINS];
   u64 gbase[PBINS];
@@ -62,13 +61,13 @@ __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, 
       u32 bin = (v[j] >> shift) & mask;
       u32 slot = S.loff[bin] + r[j];
       S.stage[slot] = v[j];
-      S.sbin[slot] = (u16)bin;
     }
   }
   __syncthreads();
   for (u32 s = threadIdx.x; s < tot; s += PSG_WG) {
-    u32 bin = S.sbin[s];
-    out[S.gbase[bin] + (s - S.loff[bin])] = S.stage[s];
+    u32 x = S.stage[s];
+    u32 bin = (x >> shift) & mask;
+    out[S.gbase[bin] + (s - S.loff[bin])] = x;
   }
   __syncthreads();
 }
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 
 
 // one work item = up to CAP log entries of one window: LDS histogram, coalesced add to the gap array
 __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap) {
-  __shared__ u32 h[WSIZE];
+  __shared__ __attribute__((aligned(16))) u32 h[WSIZE];
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
   if (threadIdx.x == 0) {  // window of this item: last w with item_pref[w] <= item
@@ -167,20 +166,39 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
     }
     s_w = lo;
   }
-  for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) h[k] = 0;
+  for (int k = threadIdx.x; k < WSIZE / 4; k += PSG_WG) ((uint4 *)h)[k] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   i64 w = s_w;
   i64 sub = item - (i64)item_pref[w];
   i64 beg = (i64)off[w] + sub * CAP, end = std::min<i64>(beg + CAP, (i64)off[w + 1]);
   bool single = (i64)(off[w + 1] - off[w]) <= CAP;
-  for (i64 k = beg + threadIdx.x; k < end; k += PSG_WG) atomicAdd(&h[keys[k] & (WSIZE - 1)], 1u);
+  for (i64 k0 = beg; k0 < end; k0 += 4 * PSG_WG) {   // 4 independent loads in flight per thread
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { i64 k = k0 + j * PSG_WG + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] & (WSIZE - 1)], 1u);
+  }
   __syncthreads();
   i64 base = w << WBITS;
-  for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) {
-    u32 c = h[k];
-    i64 idx = base + k;
-    if (c && idx <= m) {
-      if (single) gap[idx] += c; else atomicAdd(&gap[idx], c);
+  bool vec = single && base + WSIZE - 1 <= m && ((uintptr_t)(gap + base) & 15) == 0;
+  if (vec) {   // whole window inside the array: coalesced 16-byte read-modify-writes
+    for (int k = threadIdx.x; k < WSIZE / 4; k += PSG_WG) {
+      uint4 c = ((const uint4 *)h)[k];
+      if (c.x | c.y | c.z | c.w) {
+        uint4 *gp = (uint4 *)(gap + base) + k;
+        uint4 g = *gp;
+        g.x += c.x; g.y += c.y; g.z += c.z; g.w += c.w;
+        *gp = g;
+      }
+    }
+  } else {
+    for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) {
+      u32 c = h[k];
+      i64 idx = base + k;
+      if (c && idx <= m) {
+        if (single) gap[idx] += c; else atomicAdd(&gap[idx], c);
+      }
     }
   }
 }

@@ -402,6 +402,9 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
       ((uint4 *)P.log)[((u - u0 + full) >> 2) * P.K + k] = q4;
     }
   }
+  if (MODE == 2)   // a short (last) chain marks the rest of its log column as "no entry"
+    for (i64 st = ((u1 - u0) + 3) & ~(i64)3; st < P.L; st += 4)
+      ((uint4 *)P.log)[(st >> 2) * P.K + k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
   P.fin[k] = i;
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
 }
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(PSG_WG) void warmup_kernel(RankView<CNT, B> R, Warm
   do {                                                                                               \
     if ((r)->cnt == 4 && (r)->B == 48) { F<4, 48>(__VA_ARGS__); }                                    \
     else if ((r)->cnt == 16 && (r)->B == 64) { F<16, 64>(__VA_ARGS__); }                             \
+    else if ((r)->cnt == 256 && (r)->B == 32) { F<256, 32>(__VA_ARGS__); }                           \
     else if ((r)->cnt == 256 && (r)->B == 64) { F<256, 64>(__VA_ARGS__); }                           \
     else if ((r)->cnt == 256 && (r)->B == 128) { F<256, 128>(__VA_ARGS__); }                         \
     else if ((r)->cnt == 256 && (r)->B == 256) { F<256, 256>(__VA_ARGS__); }                         \
@@ -500,12 +504,21 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   if (data_bytes == 0) {
     if (sigma <= 4) { r->cnt = 4; r->B = 48; }
     else if (sigma <= 16) { r->cnt = 16; r->B = 64; }
-    else { r->cnt = 256; r->B = 64; }
+    else {
+      // general alphabet: the smaller the block, the fewer load instructions per query
+      // (B=32: counter dword + ONE dwordx4; B=64: + two; ...) at 33 / 17 / 9 / 5 bytes per symbol.
+      // Take the smallest block whose structure stays within a quarter of the free HBM.
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      double budget = 0.25 * (double)(free_b + pool_cached_bytes());
+      r->cnt = 256;
+      r->B = 33.0 * m <= budget ? 32 : 17.0 * m <= budget ? 64 : 9.0 * m <= budget ? 128 : 256;
+    }
   } else if (data_bytes == 48 && sigma <= 4) { r->cnt = 4; r->B = 48; }
   else if (data_bytes == 64 && sigma <= 16) { r->cnt = 16; r->B = 64; }
-  else if (data_bytes == 64 || data_bytes == 128 || data_bytes == 256) { r->cnt = 256; r->B = data_bytes; }
+  else if (data_bytes == 32 || data_bytes == 64 || data_bytes == 128 || data_bytes == 256) { r->cnt = 256; r->B = data_bytes; }
   else if (data_bytes == -64) { r->cnt = 256; r->B = 64; }   // force the general layout (tests)
-  else { delete r; set_error("psg_rank_build: data_bytes_per_block must be 0, 48, 64, 128, 256"); return PSG_EINVAL; }
+  else { delete r; set_error("psg_rank_build: data_bytes_per_block must be 0, 32, 48, 64, 128, 256"); return PSG_EINVAL; }
   if (r->cnt == 256) for (int c = 0; c < 256; ++c) r->code[c] = (u8)c;
   else { int k = 0; for (int c = 0; c < 256; ++c) r->code[c] = h[c] ? (u8)k++ : 0xFF; }
   r->stride = 4 * r->cnt + r->B;
@@ -684,8 +697,7 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
   if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
   DevBuf log_d;
   if (mode == 2) {
-    if ((rc = log_d.alloc(K * L * 4))) return rc;
-    PSG_HIP(hipMemsetAsync(log_d.p, 0xFF, (size_t)(K * L * 4), stream()));   // 0xFFFFFFFF = no entry
+    if ((rc = log_d.alloc(K * L * 4))) return rc;   // every entry is written by its chain (0xFFFFFFFF = no entry)
   }
   StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K};
   double kms = 0;

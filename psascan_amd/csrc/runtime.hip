@@ -58,6 +58,13 @@ void pool_free(void *p) {
   g_pool_live.erase(it);
 }
 
+size_t pool_cached_bytes() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  size_t t = 0;
+  for (auto &kv : g_pool_free) t += kv.first;
+  return t;
+}
+
 void pool_trim() {
   std::vector<void *> blocks;
   {
