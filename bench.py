@@ -12,8 +12,10 @@ The host suffix sort of the half-blocks is NOT part of the hot path (north_star:
 cores); the bench prepares the partial SAs on the device before the timed region.
 
 N > 1 (strong scaling of the same job): every rank holds the inputs; the tail is cut into N
-ranges (the reference's own parallel axis, compute_gap.hpp:68-69), each rank streams its range,
-the gap arrays are summed with one RCCL all-reduce, the gt bits are all-gathered, and each rank
+ranges (the reference's own parallel axis, compute_gap.hpp:68-69), each rank streams its range
+into a rank log; the logs are split by owner of the gap slice and exchanged with ONE RCCL
+all-to-all (4 B per streamed suffix), every rank counts its slice and marks its bits, the bit
+arrays are summed with one all-reduce (n/8 bytes), the gt bits are all-gathered, and each rank
 merges 1/N of the output.
 
 Prints ONE JSON line (rank 0).
@@ -186,9 +188,8 @@ def main():
     gt_words = max(cuts[r + 1] - cuts[r] for r in range(world)) // 32 + 4
     gap_words = ls + 2
     if world > 1:
-        gap_t = torch.zeros(gap_words, dtype=torch.int32, device="cuda")
-        gap_ptr = gap_t.data_ptr()
-        gt_all = torch.zeros((rs + 31) // 32 + 2 * world, dtype=torch.int32, device="cuda")
+        a2a_ops = D.HipA2AOps(torch, api, "cuda", full_sync=os.environ.get("PSASCAN_DIST_BACKEND", "nccl") != "nccl")
+        gt_mine = torch.zeros(gt_words, dtype=torch.int32, device="cuda")
     else:
         gap_buf = api.zeros(4 * gap_words)
         gap_ptr = gap_buf.ptr
@@ -208,24 +209,37 @@ def main():
         t = time.perf_counter()
         rk = api.rank_build(Lh["bwt"], ls, args.rank_block)
         t1 = time.perf_counter()
-        L.psg_memset(C.c_void_p(gap_ptr), 0, 4 * gap_words)
-        # rank at the right end of this range's context: exact only at n (rank of the empty suffix = 0)
-        fin, st = api.stream_gap(rk, Lh["i0"], last_left, d_text.at(tb), te - tb, gt_in, 0 if te + ctx == n else -1, gap_ptr,
-                                 gt_out, args.max_chains, right_context=ctx)
-        t2 = time.perf_counter()
-        if world > 1:
-            dist.all_reduce(gap_t)                       # sum of the per-range gap arrays (update.hpp:86-96 on all ranges)
-            # gt bits of every range (the per-round gt exchange of the block schedule)
-            mine = torch.zeros(gt_words, dtype=torch.int32, device="cuda")
-            L.psg_d2d(C.c_void_p(mine.data_ptr()), C.c_void_p(gt_out.ptr), 4 * ((te - tb + 31) // 32))
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
+        start_rank = 0 if te + ctx == n else -1   # exact only at n (rank of the empty suffix = 0)
+        if world == 1:
+            L.psg_memset(C.c_void_p(gap_ptr), 0, 4 * gap_words)
+            fin, st = api.stream_gap(rk, Lh["i0"], last_left, d_text.at(tb), te - tb, gt_in, start_rank, gap_ptr, gt_out,
+                                     args.max_chains, right_context=ctx)
+            t2 = t3 = time.perf_counter()
+            nb = api.gap_to_bitvector(gap_ptr, ls, mbv, n)
+            assert nb == n, (nb, n)
+            Lh["mbv"] = mbv
+            t4 = time.perf_counter()
+        else:
+            # gap array sharded by index range: rank-log all-to-all, slice histograms, bit all-reduce
+            # (psascan_amd/distributed.py: a2a_pass; gloo-tested in tests/test_distributed_cpu.py)
+            box = {}
+
+            def stream_log_fn(tb_r, te_r, ctx_r):
+                log, nlog, fin, st_ = api.stream_gap_log(rk, Lh["i0"], last_left, d_text.at(tb_r), te_r - tb_r, gt_in, start_rank,
+                                                         gt_mine.data_ptr(), args.max_chains, ctx_r)
+                box["st"], box["log"] = st_, log
+                box["t2"] = time.perf_counter()
+                return log.ptr, nlog, gt_mine
+
+            res = D.a2a_pass(dist, a2a_ops, world, rank, ls, mid, n, stream_log_fn, gt_words)
             torch.cuda.current_stream().synchronize()
-        t3 = time.perf_counter()
-        nb = api.gap_to_bitvector(gap_ptr, ls, mbv, n)
-        assert nb == n, (nb, n)
-        t4 = time.perf_counter()
-        Lh["mbv"] = mbv
+            box["log"].free()
+            st = box["st"]
+            assert res["nbits"] == n, (res["nbits"], n)
+            Lh["mbv"] = res["bits"].data_ptr()
+            box["keep"] = res
+            t2 = box["t2"]
+            t3 = t4 = time.perf_counter()
         plan = api.MergePlan([Lh, Rh])
         plan.run(ob, oe - ob, d_out)
         plan.free()

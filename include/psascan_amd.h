@@ -150,6 +150,34 @@ int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out)
 int psg_merge_run(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint8_t *d_out_sa5);
 void psg_merge_plan_free(psg_merge_plan_t *plan);
 
+/* ---- multi-GPU building blocks: one pass sharded over the TAIL (the reference's own parallel
+ *      axis, compute_gap.hpp:68-69,114-124), the gap array sharded by index range.  Each rank
+ *      streams its tail range into a rank log, the logs are exchanged so that every rank holds
+ *      the entries of its gap slice (all-to-all), and slices are counted / turned into
+ *      bitvector bits locally.  These replace the shared gap array + updater of
+ *      update.hpp:60-220 across devices.                                                   ---- */
+/* stream a tail range; instead of counting, hand back the log: *nlog u32 entries (0xFFFFFFFF =
+ * no entry, arbitrary order) in a device buffer the caller releases with psg_free.           */
+int psg_stream_gap_log(const psg_rank_t *rank, int64_t block_i0, int block_last_symbol,
+                       const uint8_t *d_tail, int64_t tail_len, int64_t right_context,
+                       const uint32_t *d_gt_in, int64_t rank_at_context_end, uint32_t *d_gt_out,
+                       int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats,
+                       uint32_t **d_log, int64_t *nlog);
+/* split the valid entries into nparts contiguous value ranges: part p occupies
+ * d_out[h_offsets[p] .. h_offsets[p+1]) and holds the values [h_value_bounds[p],
+ * h_value_bounds[p+1]); the bounds depend only on (m, nparts).                              */
+int psg_log_partition(const uint32_t *d_log, int64_t nlog, int64_t m, int nparts, uint32_t *d_out,
+                      int64_t *h_offsets, int64_t *h_value_bounds);
+/* d_gap_slice[v - value_base] += #{log entries equal to v}, v in [value_base, value_base+count);
+ * the log is clobbered.                                                                     */
+int psg_gap_hist(uint32_t *d_log, int64_t nlog, int64_t value_base, int64_t count, uint32_t *d_gap_slice);
+/* slice form of convert_to_bitvector: sets bit j + ps_before + sum_{t in slice, t<=j} gap[t] for
+ * every j in [j0, j0+count) with j < m in a ZERO-initialised array of the global size; after
+ * summing the arrays of all ranks (disjoint bits) psg_bits_not gives the bitvector.          */
+int psg_gap_slice_to_bits(const uint32_t *d_gap_slice, int64_t j0, int64_t count, int64_t m,
+                          uint64_t ps_before, uint32_t *d_bits);
+int psg_bits_not(uint32_t *d_bits, int64_t nbits);
+
 /* ---- small device utilities the host orchestration needs ------------------------------ */
 /* dst bits [dst_bit, dst_bit+nbits) = src bits [src_bit, src_bit+nbits) (non-overlapping) */
 int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t src_bit, int64_t nbits);

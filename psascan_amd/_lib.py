@@ -43,6 +43,12 @@ SIGNATURES = {
     "psg_rank_free": (None, [_vp]),
     "psg_stream_gap": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_stream_gap_ctx": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_stream_gap_log": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC),
+                                  C.POINTER(_vp), C.POINTER(_i64)]),
+    "psg_log_partition": (_int, [_vp, _i64, _i64, _int, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "psg_gap_hist": (_int, [_vp, _i64, _i64, _i64, _vp]),
+    "psg_gap_slice_to_bits": (_int, [_vp, _i64, _i64, _i64, C.c_uint64, _vp]),
+    "psg_bits_not": (_int, [_vp, _i64]),
     "psg_gap_to_bitvector": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "psg_merge_bwt": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, C.POINTER(_i64)]),
     "psg_split_gap": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

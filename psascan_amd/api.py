@@ -215,3 +215,40 @@ def popcount(d_bits, nbits):
 
 def last_kernel_ms():
     return lib().psg_last_kernel_ms()
+
+
+# ---- multi-GPU building blocks (include/psascan_amd.h, "multi-GPU building blocks") ----
+class BorrowedBuffer(DeviceBuffer):
+    """A device buffer allocated inside the library and handed to the caller (released with psg_free)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, int(nbytes)
+
+
+def stream_gap_log(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_context_end, d_gt_out,
+                   max_chains=0, right_context=0):
+    """Stream a tail range and return its rank log: (log buffer of nlog u32, nlog, final_rank, stats)."""
+    fin, st, p, n = C.c_int64(0), StreamStatsC(), C.c_void_p(), C.c_int64(0)
+    check(lib().psg_stream_gap_log(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context, _ptr(d_gt_in),
+                                   rank_at_context_end, _ptr(d_gt_out), max_chains, C.byref(fin), C.byref(st), C.byref(p), C.byref(n)))
+    return BorrowedBuffer(p.value, 4 * n.value), n.value, fin.value, StreamStats(st)
+
+
+def log_partition(d_log, nlog, m, nparts, d_out):
+    """-> (offsets[nparts+1], value_bounds[nparts+1])"""
+    offs = (C.c_int64 * (nparts + 1))()
+    vb = (C.c_int64 * (nparts + 1))()
+    check(lib().psg_log_partition(_ptr(d_log), nlog, m, nparts, _ptr(d_out), offs, vb))
+    return list(offs), list(vb)
+
+
+def gap_hist(d_log, nlog, value_base, count, d_gap_slice):
+    check(lib().psg_gap_hist(_ptr(d_log), nlog, value_base, count, _ptr(d_gap_slice)))
+
+
+def gap_slice_to_bits(d_gap_slice, j0, count, m, ps_before, d_bits):
+    check(lib().psg_gap_slice_to_bits(_ptr(d_gap_slice), j0, count, m, ps_before, _ptr(d_bits)))
+
+
+def bits_not(d_bits, nbits):
+    check(lib().psg_bits_not(_ptr(d_bits), nbits))

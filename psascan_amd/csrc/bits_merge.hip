@@ -131,6 +131,74 @@ extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *
   return 0;
 }
 
+// ---- slice form for the multi-GPU driver: rank d owns gap[j0 .. j0+count) and knows how many
+// tail suffixes fall into lower slices (ps_before).  It marks its own zero-bit positions
+// j + ps_before + sum_{t<=j, t in slice} gap[t] with ONE bits in a zero-initialised array of the
+// global size; the arrays of all ranks are summed (disjoint bits -> OR) and inverted.
+__global__ __launch_bounds__(PSG_WG) void gap_slice_bits_kernel(const u32 *gap, i64 j0, i64 count, i64 m, u64 ps_before,
+                                                                  const u64 *tile_pref, u32 *bits) {
+  __shared__ u64 scratch[8];
+  __shared__ u32 win[BMW];
+  __shared__ i64 base_word;
+  i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
+  u32 g[8];
+  u64 s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { g[q] = base + q < count ? gap[base + q] : 0; s += g[q]; }
+  u64 tot;
+  u64 tp = ps_before + tile_pref[blockIdx.x];
+  u64 pre = tp + block_excl_scan<u64>(s, scratch, tot);
+  for (int k = threadIdx.x; k < BMW; k += PSG_WG) win[k] = 0;
+  if (threadIdx.x == 0) base_word = (j0 + (i64)blockIdx.x * TILE_V + (i64)tp) >> 5;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    pre += g[q];
+    i64 j = j0 + base + q;
+    if (base + q < count && j < m) {
+      i64 pos = j + (i64)pre, k = (pos >> 5) - base_word;
+      if (k >= 0 && k < BMW) atomicOr(&win[k], 1u << (pos & 31));
+      else atomicOr(&bits[pos >> 5], 1u << (pos & 31));
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < BMW; k += PSG_WG) if (win[k]) atomicOr(&bits[base_word + k], win[k]);
+}
+
+extern "C" int psg_gap_slice_to_bits(const uint32_t *d_gap_slice, int64_t j0, int64_t count, int64_t m, uint64_t ps_before,
+                                     uint32_t *d_bits) {
+  PSG_REQUIRE(d_bits && j0 >= 0 && count >= 0 && m >= 0, "psg_gap_slice_to_bits");
+  if (count == 0) return 0;
+  PSG_REQUIRE(d_gap_slice, "psg_gap_slice_to_bits: slice required");
+  i64 ntiles = cdiv(count, TILE_V);
+  DevBuf ts;
+  int rc;
+  if ((rc = ts.alloc(ntiles * 8))) return rc;
+  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, count, ts.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, nullptr))) return rc;
+  hipLaunchKernelGGL(gap_slice_bits_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, j0, count, m, (u64)ps_before,
+                     ts.as<u64>(), d_bits);
+  PSG_HIP(hipGetLastError());
+  PSG_HIP(hipStreamSynchronize(stream()));
+  return 0;
+}
+
+__global__ __launch_bounds__(PSG_WG) void bits_not_kernel(u32 *bits, i64 nbits) {
+  i64 w = (i64)blockIdx.x * PSG_WG + threadIdx.x, nw = (nbits + 31) >> 5;
+  if (w >= nw) return;
+  u32 x = ~bits[w];
+  if (w == nw - 1 && (nbits & 31)) x &= (1u << (nbits & 31)) - 1u;
+  bits[w] = x;
+}
+extern "C" int psg_bits_not(uint32_t *d_bits, int64_t nbits) {
+  PSG_REQUIRE(d_bits && nbits >= 0, "psg_bits_not");
+  if (nbits == 0) return 0;
+  hipLaunchKernelGGL(bits_not_kernel, dim3((unsigned)cdiv((nbits + 31) >> 5, PSG_WG)), dim3(PSG_WG), 0, stream(), d_bits, nbits);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
 // =======================================================================================
 // K4: BWT merge
 // =======================================================================================

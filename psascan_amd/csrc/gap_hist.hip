@@ -251,6 +251,70 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// multi-GPU building blocks (tail-sharded pass with a rank-log all-to-all)
+// ---------------------------------------------------------------------------------------
+static void level1_geometry(i64 m, int *shift1, int *bits2) {
+  const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;
+  int bits_total = 0;
+  while (((i64)1 << bits_total) < nwin) ++bits_total;
+  *bits2 = bits_total > 9 ? bits_total - 9 : 0;
+  *shift1 = WBITS + *bits2;
+}
+
+// Split the valid entries of a rank log into `nparts` contiguous value ranges (part p = level-1
+// bins [nb*p/nparts, nb*(p+1)/nparts), nb = bins in use): d_out receives the parts back to back, h_offsets[p] is the
+// start of part p in d_out (h_offsets[nparts] = number of valid entries), h_value_bounds[p] the
+// first value of part p.  The bounds depend only on (m, nparts), so every rank computes the same.
+extern "C" int psg_log_partition(const uint32_t *d_log, int64_t nlog, int64_t m, int nparts, uint32_t *d_out,
+                                 int64_t *h_offsets, int64_t *h_value_bounds) {
+  PSG_REQUIRE(d_out && h_offsets && h_value_bounds && nlog >= 0 && m >= 0 && m < 0xFFFFFFFFll && nparts >= 1 && nparts <= PBINS,
+              "psg_log_partition");
+  int shift1, bits2;
+  level1_geometry(m, &shift1, &bits2);
+  const i64 nb = ((m + 1) + ((i64)1 << shift1) - 1) >> shift1;   // level-1 bins that can hold a value (<= 512)
+  for (int p = 0; p <= nparts; ++p) {
+    i64 v = (nb * p / nparts) << shift1;
+    h_value_bounds[p] = p == nparts ? std::max<i64>(v, m + 1) : v;
+  }
+  if (nlog == 0) { for (int p = 0; p <= nparts; ++p) h_offsets[p] = 0; return 0; }
+  PSG_REQUIRE(d_log, "psg_log_partition: log required");
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, PT)));
+  DevBuf counts, off, bin_base;
+  int rc;
+  if ((rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) || (rc = bin_base.alloc((PBINS + 1) * 8))) return rc;
+  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
+  hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
+  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, off.as<u64>(), d_out);
+  PSG_HIP(hipGetLastError());
+  u64 bb[PBINS + 1];
+  PSG_HIP(hipMemcpyAsync(bb, bin_base.p, sizeof bb, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipStreamSynchronize(stream()));
+  for (int p = 0; p <= nparts; ++p) h_offsets[p] = (i64)bb[p == nparts ? PBINS : nb * p / nparts];
+  return 0;
+}
+
+__global__ __launch_bounds__(PSG_WG) void sub_base_kernel(u32 *log, i64 n, u32 base, u32 count) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k >= n) return;
+  u32 v = log[k];
+  log[k] = (v != PAD && v >= base && v - base < count) ? v - base : PAD;
+}
+
+// gap_slice[v - value_base] += #{entries equal to v} for v in [value_base, value_base + count);
+// other entries are ignored; the log is clobbered.
+extern "C" int psg_gap_hist(uint32_t *d_log, int64_t nlog, int64_t value_base, int64_t count, uint32_t *d_gap_slice) {
+  PSG_REQUIRE(d_gap_slice && nlog >= 0 && value_base >= 0 && count >= 0 && value_base + count <= 0xFFFFFFFFll, "psg_gap_hist");
+  if (nlog == 0 || count == 0) return 0;
+  PSG_REQUIRE(d_log, "psg_gap_hist: log required");
+  hipLaunchKernelGGL(sub_base_kernel, dim3((unsigned)cdiv(nlog, PSG_WG)), dim3(PSG_WG), 0, stream(), d_log, nlog, (u32)value_base, (u32)count);
+  PSG_HIP(hipGetLastError());
+  return psg::gap_hist_from_log(d_log, nlog, count - 1, d_gap_slice, nullptr);
+}
+
 // test entry (include/psascan_amd_extras.h): histogram an explicit rank log
 extern "C" int psgx_gap_hist(uint32_t *d_log, int64_t nlog, int64_t m, uint32_t *d_gap) {
   PSG_REQUIRE(d_log && d_gap && nlog >= 0 && m >= 0 && m < 0xFFFFFFFFll, "psgx_gap_hist");

@@ -626,11 +626,35 @@ extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, con
   return psg_stream_gap_ctx(r, i0, last_sym, d_tail, T, 0, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats);
 }
 
+static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
+                       const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
+                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out);
+
 extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                                   int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
                                   uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
+  PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
+  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr);
+}
+
+// same pass, but the ranks are handed back as a log (one u32 per streamed suffix, 0xFFFFFFFF =
+// no entry, arbitrary order) instead of being counted: the multi-GPU driver partitions the log by
+// owner of the gap slice and exchanges it (all-to-all) before histogramming.
+extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
+                                  int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gt_out,
+                                  int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **d_log,
+                                  int64_t *nlog) {
+  PSG_REQUIRE(d_log && nlog, "psg_stream_gap_log: output pointers required");
+  PSG_REQUIRE(r && r->m < 0xFFFFFFFFll, "psg_stream_gap_log: block too large for a 32-bit rank log");
+  *d_log = nullptr; *nlog = 0;
+  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, h_final_rank, stats, d_log, nlog);
+}
+
+static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
+                       const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
+                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out) {
   PSG_REQUIRE(ctx >= 0 && (ctx & 63) == 0, "psg_stream_gap_ctx: right context must be a multiple of 64");
-  PSG_REQUIRE(r && d_gap, "psg_stream_gap: rank and gap required");
+  PSG_REQUIRE(r && (d_gap || log_out), "psg_stream_gap: rank and gap required");
   PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");
   PSG_REQUIRE((rank_at_end >= 0 && rank_at_end <= r->m) || (rank_at_end == -1 && ctx > 0),
               "psg_stream_gap: rank_at_tail_end out of range (-1 = unknown is only allowed with a right context)");
@@ -651,6 +675,7 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
     bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
     if (e && !strcmp(e, "atomic")) want_log = false;
     if (want_log && r->m < 0xFFFFFFFFll && mode == 0) mode = 2;
+    if (log_out) mode = 2;   // the caller wants the log itself
   }
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
   // pass time: every chain has the same length)
@@ -740,7 +765,11 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
     }
   if (ctx == 0 && lo[0] != rank_at_end) { set_error("stream: chain 0 did not start at rank_at_tail_end"); return PSG_ECHECK; }
   double hist_ms = 0;
-  if (mode == 2) {
+  if (mode == 2 && log_out) {       // hand the log to the caller (ownership moves; psg_free)
+    *log_out = log_d.as<u32>();
+    *nlog_out = K * L;
+    log_d.p = nullptr;
+  } else if (mode == 2) {
     if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms))) return rc;
     log_d.alloc(16);   // give the log back to the pool before returning
   }

@@ -65,6 +65,108 @@ WORKER = textwrap.dedent("""
 """)
 
 
+WORKER_A2A = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import orc
+    from psascan_amd import distributed as D
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    rng = np.random.default_rng(9)
+    n = 400000
+    t = rng.integers(0, 4, n, dtype=np.uint8)
+    b, mid, e = 1000, 150000, 390001                  # block [b,mid), tail [mid,e)
+    sa = orc.suffix_array(t); isa = orc.inverse(sa)
+    psa, bwt, i0, _ = orc.partial_sa(t, sa, isa, b, mid)
+    m = mid - b
+    rk = orc.Rank(bwt)
+    def gt_bits(hi, lo):
+        return orc.packbits((np.concatenate([isa, [-1]])[np.arange(hi, lo, -1)] > isa[mid]).astype(np.uint8).tolist() + [0] * 64)
+    def rank_at(p):
+        return int((isa[b:mid] < (isa[p] if p < n else -1)).sum())
+    SH, PB = 14, 512                                   # window bits / level-1 bins of the HIP partition
+
+    class Ops:                                         # numpy stand-ins with the semantics of the C ABI entry points
+        def new_i32(self, k): return torch.zeros(int(k), dtype=torch.int32)
+        def i64_from(self, v): return torch.tensor(v, dtype=torch.int64)
+        def partition(self, log, nlog, m, world):
+            v = log.numpy().view(np.uint32)[:nlog]; v = v[v != 0xFFFFFFFF]
+            nwin = (m + 1 + (1 << SH) - 1) >> SH
+            bits = int(np.ceil(np.log2(nwin))) if nwin > 1 else 0
+            shift1 = SH + max(0, bits - 9)
+            nb = ((m + 1) + (1 << shift1) - 1) >> shift1
+            vb = [((nb * p // world) << shift1) for p in range(world)] + [max((nb << shift1), m + 1)]
+            order = np.argsort(v >> shift1, kind="stable")
+            v = v[order]
+            offs = [int(np.searchsorted(v, vb[p])) for p in range(world)] + [len(v)]
+            out = torch.zeros(max(len(v), 1), dtype=torch.int32); out[: len(v)] = torch.from_numpy(v.view(np.int32))
+            return out, offs, vb
+        def hist_slice(self, recv_t, nrecv, base, count):
+            v = recv_t.numpy().view(np.uint32)[:nrecv].astype(np.int64) - base
+            assert ((v >= 0) & (v < max(count, 1))).all()
+            return torch.from_numpy(np.bincount(v, minlength=max(count, 1)).astype(np.int32))
+        def slice_to_bits(self, gap_slice, j0, count, m, ps_before, nbits):
+            g = gap_slice.numpy()[:count].astype(np.int64)
+            pos = j0 + np.arange(count) + ps_before + np.cumsum(g)
+            pos = pos[(j0 + np.arange(count)) < m]
+            bits = np.zeros(((nbits + 31) // 32 + 2) * 32, np.uint8); bits[pos] = 1
+            return torch.from_numpy(np.packbits(bits, bitorder="little").view(np.int32).copy())
+        def bits_not(self, bits, nbits):
+            x = np.unpackbits(bits.numpy().view(np.uint8), bitorder="little"); x[:nbits] ^= 1; x[nbits:] = 0
+            bits[:] = torch.from_numpy(np.packbits(x, bitorder="little").view(np.int32).copy())
+    ops = Ops()
+    T = e - mid
+    words = (T // world + 64) // 32 + 4
+    def stream_log_fn(tb_r, te_r, ctx):
+        g, gto, fin = orc.stream_pass(rk, i0, int(t[mid - 1]), t, tb_r, te_r, gt_bits(te_r, tb_r), rank_at(te_r))
+        log = np.repeat(np.arange(m + 1, dtype=np.uint32), g.astype(np.int64))     # the multiset of ranks = the log
+        log = np.concatenate([log, np.full(37, 0xFFFFFFFF, np.uint32)]); rng.shuffle(log)
+        out = torch.zeros(words, dtype=torch.int32)
+        raw = np.zeros(words * 4, np.uint8); raw[: len(gto)] = gto[: words * 4]
+        out[:] = torch.from_numpy(raw.view(np.int32))
+        return torch.from_numpy(log.view(np.int32).copy()), len(log), out
+    res = D.a2a_pass(dist, ops, world, rank, m, mid, e, stream_log_fn, words)
+    want_gap, want_gt, _ = orc.stream_pass(rk, i0, int(t[mid - 1]), t, mid, e, gt_bits(e, mid), rank_at(e))
+    base, count = res["base"], res["count"]
+    assert np.array_equal(res["gap_slice"].numpy()[:count].astype(np.uint64), want_gap[base: base + count])
+    assert res["streamed"] == T and res["nbits"] == m + T
+    want_bv, nb = orc.gap_to_bitvector(want_gap, m)
+    assert nb == res["nbits"]
+    assert np.array_equal(orc.bits(res["bits"].numpy().view(np.uint8), nb), orc.bits(want_bv, nb))
+    bits = [orc.bits(p.numpy().view(np.uint8), res["cuts"][r + 1] - res["cuts"][r]) for r, p in enumerate(res["gt_parts"])]
+    assert np.array_equal(D.assemble_gt(bits, res["cuts"], e), orc.bits(want_gt, T))
+    assert sum(res["send"]) == res["cuts"][rank + 1] - res["cuts"][rank]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("WORKER_OK", rank)
+""")
+
+
+def _run_workers(tmp_path, src, world):
+    script = tmp_path / "worker.py"
+    script.write_text(src.format(root=ROOT))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-3000:]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_a2a_pass_gloo(tmp_path, world):
+    """gap array sharded by index range: rank-log all-to-all + slice histograms + bit all-reduce."""
+    _run_workers(tmp_path, WORKER_A2A, world)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -162,6 +162,73 @@ def test_gap_hist_from_log(A, gpu_lib, m, nlog, skew):
     assert np.array_equal(A.download(d_gap, np.uint32, m + 1), want)
 
 
+@pytest.mark.parametrize("kind,nparts", [("sig4z", 3), ("rand255", 4), ("alla", 2)])
+def test_multi_gpu_building_blocks(A, kind, nparts):
+    """stream_gap_log over tail sub-ranges -> log_partition -> (exchange emulated on one device)
+    -> gap_hist per slice -> gap_slice_to_bits -> sum -> bits_not  ==  oracle gap array / bitvector."""
+    from psascan_amd import distributed as D
+    n = 120000 if kind != "alla" else 40000
+    t = make_text(kind, n, 33)
+    b, e = 2000, 2000 + n // 3
+    bwt, i0, gt_all, init = _stream_case(t, b, e, e, n)
+    m = e - b
+    T = n - e
+    want_gap, want_gt, _ = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_all, init)
+    want_bv, nbits = orc.gap_to_bitvector(want_gap, m)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text = A.upload(t, pad_to=16)
+    d_gt_all = A.upload(gt_all, pad_to=8)
+    cuts = D.tail_cuts(e, n, nparts)
+    parts, offs_all, vb = [], [], None
+    gt_got = np.zeros(T, np.uint8)
+    for rk in range(nparts):                         # "rank" rk streams its range
+        tb_r, te_r = cuts[rk], cuts[rk + 1]
+        ctx = D.context_len(te_r, n) if kind != "alla" else 0
+        L = te_r + ctx - tb_r
+        d_gt_in = A.zeros(4 * ((L + 31) // 32 + 2))
+        A.bitcopy(d_gt_in, 0, d_gt_all, n - (te_r + ctx), L)
+        d_gt_out = A.zeros(4 * ((te_r - tb_r + 31) // 32 + 2))
+        if te_r + ctx == n:
+            start = 0
+        elif kind == "alla":                          # repetitive text: no context, exact start rank from the definition
+            sa = orc.suffix_array(t); isa = orc.inverse(sa)
+            start = int((isa[b:e] < isa[te_r]).sum())
+        else:
+            start = -1
+        log, nlog, fin, st = A.stream_gap_log(r, i0, t[e - 1], d_text.at(tb_r), te_r - tb_r, d_gt_in, start, d_gt_out, 64, ctx)
+        gt_got[n - te_r: n - tb_r] = orc.bits(A.download(d_gt_out, np.uint8, (te_r - tb_r + 7) // 8), te_r - tb_r)
+        d_part = A.DeviceBuffer(4 * max(nlog, 1))
+        offs, vb_r = A.log_partition(log, nlog, m, nparts, d_part)
+        assert vb is None or vb == vb_r
+        vb = vb_r
+        assert offs[-1] == te_r - tb_r
+        parts.append(A.download(d_part, np.uint32, offs[-1]))
+        offs_all.append(offs)
+    assert np.array_equal(gt_got, orc.bits(want_gt, T))
+    bits_sum = np.zeros((nbits + 31) // 32 + 2, np.uint32)
+    totals = []
+    slices = []
+    for d in range(nparts):                          # "rank" d receives its parts
+        recv = np.concatenate([parts[s][offs_all[s][d]: offs_all[s][d + 1]] for s in range(nparts)])
+        base = vb[d]
+        count = max(0, min(vb[d + 1], m + 1) - base)
+        d_slice = A.zeros(4 * max(count, 1))
+        A.gap_hist(A.upload(recv) if len(recv) else None, len(recv), base, count, d_slice)
+        got = A.download(d_slice, np.uint32, count)
+        assert np.array_equal(got.astype(np.uint64), want_gap[base: base + count])
+        totals.append(len(recv)); slices.append((d_slice, base, count))
+    assert sum(totals) == T
+    for d, (d_slice, base, count) in enumerate(slices):
+        d_bits = A.zeros(4 * len(bits_sum))
+        A.gap_slice_to_bits(d_slice, base, count, m, sum(totals[:d]), d_bits)
+        part_bits = A.download(d_bits, np.uint32, len(bits_sum))
+        assert not (bits_sum & part_bits).any()      # disjoint -> sum == or
+        bits_sum += part_bits
+    d_all = A.upload(bits_sum)
+    A.bits_not(d_all, nbits)
+    assert np.array_equal(orc.bits(A.download(d_all, np.uint8, (nbits + 7) // 8), nbits), orc.bits(want_bv, nbits))
+
+
 def test_stream_gap_empty_tail(A):
     bwt = np.array([0, 1, 2, 1], np.uint8)
     r = A.rank_build(A.upload(bwt, pad_to=16), 4)
