@@ -20,7 +20,8 @@ using namespace psg;
 #define WSIZE (1 << WBITS)
 #define CAP (1 << 17)      // log entries per histogram work item
 #define PBINS 512          // bins per partition level
-#define PT 8192            // entries per partition tile (32 per thread)
+#define PT 8192            // entries per partition tile
+#define PNT 1024           // threads of a partition workgroup (8 entries per thread and tile)
 #define PAD 0xFFFFFFFFu
 
 struct Tile {              // LDS of one partition workgroup (~44 KiB -> 3 workgroups per CU)
@@ -29,34 +30,47 @@ struct Tile {              // LDS of one partition workgroup (~44 KiB -> 3 workg
   u32 loff[PBINS];
   u64 gbase[PBINS];
   u64 cur[PBINS];
-  u32 scratch[8];
+  u32 scratch[PNT / 64];
 };
+
+// exclusive scan over the PNT threads of a partition workgroup
+__device__ __forceinline__ u32 part_scan(u32 v, u32 *scratch, u32 &total) {
+  u32 inc = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < PNT / 64; ++k) { u32 x = scratch[k]; if (k < w) base += x; tot += x; }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
 
 // scatter one tile [beg, end) (end - beg <= PT) of `keys` into `out` at the workgroup's cursors
 __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, i64 end, int shift, u32 mask, u32 *out) {
-  u32 v[PT / PSG_WG];
-  u32 r[PT / PSG_WG];
-  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.h[b] = 0;
+  u32 v[PT / PNT];
+  u32 r[PT / PNT];
+  for (int b = threadIdx.x; b < PBINS; b += PNT) S.h[b] = 0;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < PT / PSG_WG; ++j) {
-    i64 k = beg + j * PSG_WG + threadIdx.x;
+  for (int j = 0; j < PT / PNT; ++j) {
+    i64 k = beg + j * PNT + threadIdx.x;
     v[j] = k < end ? keys[k] : PAD;
     if (v[j] != PAD) r[j] = atomicAdd(&S.h[(v[j] >> shift) & mask], 1u);
   }
   __syncthreads();
-  // exclusive scan over the 512 bins (2 per thread) + advance the cursors
-  u32 a = S.h[2 * threadIdx.x], b2 = S.h[2 * threadIdx.x + 1], tot;
-  u32 pre = block_excl_scan<u32>(a + b2, S.scratch, tot);
-  S.loff[2 * threadIdx.x] = pre;
-  S.loff[2 * threadIdx.x + 1] = pre + a;
-  S.gbase[2 * threadIdx.x] = S.cur[2 * threadIdx.x];
-  S.gbase[2 * threadIdx.x + 1] = S.cur[2 * threadIdx.x + 1];
-  S.cur[2 * threadIdx.x] += a;
-  S.cur[2 * threadIdx.x + 1] += b2;
+  // exclusive scan over the 512 bins (one per thread < 512) + advance the cursors
+  u32 hb = threadIdx.x < PBINS ? S.h[threadIdx.x] : 0, tot;
+  u32 pre = part_scan(hb, S.scratch, tot);
+  if (threadIdx.x < PBINS) {
+    S.loff[threadIdx.x] = pre;
+    S.gbase[threadIdx.x] = S.cur[threadIdx.x];
+    S.cur[threadIdx.x] += hb;
+  }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < PT / PSG_WG; ++j) {
+  for (int j = 0; j < PT / PNT; ++j) {
     if (v[j] != PAD) {
       u32 bin = (v[j] >> shift) & mask;
       u32 slot = S.loff[bin] + r[j];
@@ -64,7 +78,7 @@ __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, 
     }
   }
   __syncthreads();
-  for (u32 s = threadIdx.x; s < tot; s += PSG_WG) {
+  for (u32 s = threadIdx.x; s < tot; s += PNT) {
     u32 x = S.stage[s];
     u32 bin = (x >> shift) & mask;
     out[S.gbase[bin] + (s - S.loff[bin])] = x;
@@ -73,23 +87,23 @@ __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, 
 }
 
 // level 1, step A: persistent workgroup g counts its tiles (g, g+G, ...)
-__global__ __launch_bounds__(PSG_WG) void part_count_kernel(const u32 *keys, i64 n, int shift, u32 *counts) {
+__global__ __launch_bounds__(PNT) void part_count_kernel(const u32 *keys, i64 n, int shift, u32 *counts) {
   __shared__ u32 h[PBINS];
-  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) h[b] = 0;
+  for (int b = threadIdx.x; b < PBINS; b += PNT) h[b] = 0;
   __syncthreads();
   i64 ntiles = (n + PT - 1) / PT;
   for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     i64 beg = tile * PT;
-    for (int j0 = 0; j0 < PT / PSG_WG; j0 += 8) {   // 8 independent loads in flight, then the LDS atomics
+    for (int j0 = 0; j0 < PT / PNT; j0 += 8) {   // 8 independent loads in flight, then the LDS atomics
       u32 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { i64 k = beg + (j0 + j) * PSG_WG + threadIdx.x; v[j] = k < n ? keys[k] : PAD; }
+      for (int j = 0; j < 8; ++j) { i64 k = beg + (j0 + j) * PNT + threadIdx.x; v[j] = k < n ? keys[k] : PAD; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] >> shift], 1u);
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) counts[(i64)blockIdx.x * PBINS + b] = h[b];
+  for (int b = threadIdx.x; b < PBINS; b += PNT) counts[(i64)blockIdx.x * PBINS + b] = h[b];
 }
 
 // level 1, step B (one workgroup of 512 threads): off[g][b] = start of workgroup g's run inside bin b
@@ -112,9 +126,9 @@ __global__ __launch_bounds__(PBINS) void part_offsets_kernel(const u32 *counts, 
 }
 
 // level 1, step C: persistent workgroup g scatters its tiles at its private cursors
-__global__ __launch_bounds__(PSG_WG) void part_scatter_kernel(const u32 *keys, i64 n, int shift, const u64 *off, u32 *out) {
+__global__ __launch_bounds__(PNT) void part_scatter_kernel(const u32 *keys, i64 n, int shift, const u64 *off, u32 *out) {
   __shared__ Tile S;
-  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.cur[b] = off[(i64)blockIdx.x * PBINS + b];
+  for (int b = threadIdx.x; b < PBINS; b += PNT) S.cur[b] = off[(i64)blockIdx.x * PBINS + b];
   __syncthreads();
   i64 ntiles = (n + PT - 1) / PT;
   for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
@@ -122,26 +136,25 @@ __global__ __launch_bounds__(PSG_WG) void part_scatter_kernel(const u32 *keys, i
 }
 
 // level 2: workgroup b splits segment b of level 1 by the next bits; records the window starts
-__global__ __launch_bounds__(PSG_WG) void part_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, u32 *out, u64 *win_off) {
+__global__ __launch_bounds__(PNT) void part_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, u32 *out, u64 *win_off) {
   __shared__ Tile S;
   const i64 sb = (i64)bin_base[blockIdx.x], se = (i64)bin_base[blockIdx.x + 1];
   const u32 mask = (1u << bits2) - 1u;
-  for (int b = threadIdx.x; b < PBINS; b += PSG_WG) S.h[b] = 0;
+  for (int b = threadIdx.x; b < PBINS; b += PNT) S.h[b] = 0;
   __syncthreads();
-  for (i64 k0 = sb; k0 < se; k0 += 8 * PSG_WG) {
+  for (i64 k0 = sb; k0 < se; k0 += 8 * PNT) {
     u32 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * PSG_WG + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
+    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * PNT + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.h[(v[j] >> WBITS) & mask], 1u);
   }
   __syncthreads();
-  u32 a = S.h[2 * threadIdx.x], b2 = S.h[2 * threadIdx.x + 1], tot;
-  u32 pre = block_excl_scan<u32>(a + b2, S.scratch, tot);
-  S.cur[2 * threadIdx.x] = (u64)sb + pre;
-  S.cur[2 * threadIdx.x + 1] = (u64)sb + pre + a;
+  u32 hb = threadIdx.x < PBINS ? S.h[threadIdx.x] : 0, tot;
+  u32 pre = part_scan(hb, S.scratch, tot);
+  if (threadIdx.x < PBINS) S.cur[threadIdx.x] = (u64)sb + pre;
   __syncthreads();
-  for (u32 c = threadIdx.x; c <= mask; c += PSG_WG) win_off[((i64)blockIdx.x << bits2) + c] = S.cur[c];
+  for (u32 c = threadIdx.x; c <= mask; c += PNT) win_off[((i64)blockIdx.x << bits2) + c] = S.cur[c];
   __syncthreads();
   for (i64 beg = sb; beg < se; beg += PT) scatter_tile(S, keys, beg, std::min<i64>(beg + PT, se), WBITS, mask, out);
 }
@@ -221,15 +234,15 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   if ((rc = part1.alloc(nlog * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
       (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
     return rc;
-  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
+  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
   hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
-  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, off.as<u64>(), part1.as<u32>());
+  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, off.as<u64>(), part1.as<u32>());
   PSG_HIP(hipGetLastError());
   const u32 *sorted = part1.as<u32>();
   const u64 *woff = bin_base.as<u64>();
   if (bits2) {
     // the log buffer itself is free now: reuse it as the level-2 output
-    hipLaunchKernelGGL(part_level2_kernel, dim3(PBINS), dim3(PSG_WG), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, d_log, win_off.as<u64>());
+    hipLaunchKernelGGL(part_level2_kernel, dim3(PBINS), dim3(PNT), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, d_log, win_off.as<u64>());
     PSG_HIP(hipMemcpyAsync(win_off.as<u64>() + nwin_slots, bin_base.as<u64>() + PBINS, 8, hipMemcpyDeviceToDevice, stream()));
     PSG_HIP(hipGetLastError());
     sorted = d_log;
@@ -286,9 +299,9 @@ extern "C" int psg_log_partition(const uint32_t *d_log, int64_t nlog, int64_t m,
   DevBuf counts, off, bin_base;
   int rc;
   if ((rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) || (rc = bin_base.alloc((PBINS + 1) * 8))) return rc;
-  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
+  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
   hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
-  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PSG_WG), 0, stream(), d_log, nlog, shift1, off.as<u64>(), d_out);
+  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, off.as<u64>(), d_out);
   PSG_HIP(hipGetLastError());
   u64 bb[PBINS + 1];
   PSG_HIP(hipMemcpyAsync(bb, bin_base.p, sizeof bb, hipMemcpyDeviceToHost, stream()));

@@ -510,7 +510,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
       // Take the smallest block whose structure stays within a quarter of the free HBM.
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
-      double budget = 0.25 * (double)(free_b + pool_cached_bytes());
+      double budget = 0.35 * (double)(free_b + pool_cached_bytes());
       r->cnt = 256;
       r->B = 33.0 * m <= budget ? 32 : 17.0 * m <= budget ? 64 : 9.0 * m <= budget ? 128 : 256;
     }

@@ -33,3 +33,19 @@ def check_sa5(d_text, n, d_sa5, count, samples=1 << 20, seed=7):
     bad, s = C.c_int64(0), C.c_uint64(0)
     check(lib().psgx_check_sa5(_ptr(d_text), n, _ptr(d_sa5), count, samples, seed, C.byref(bad), C.byref(s)))
     return bad.value, s.value
+
+
+class DeviceSorter:
+    """Sorter for psascan_amd.pipeline.construct_sa5 that keeps everything in HBM (prefix-key radix
+    sort: texts with short repeats only).  Stands where the host sorter stands; used by the
+    full-size property tests and the bench, never by construct_sa."""
+    device = True
+
+    def __init__(self, d_text, n):
+        self.d_text, self.n = d_text, n
+        self.tie_groups = 0
+
+    def __call__(self, text, beg, end, gt_tail):
+        r = sort_halfblock(self.d_text, self.n, beg, end)
+        self.tie_groups += r["tie_groups"]
+        return {"device": True, "psa_lo": r["psa_lo"], "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": end - beg}

@@ -66,21 +66,39 @@ class _GtReader:
         return self.fn(v)
 
 
-def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=None):
-    """Whole run on one GPU.  Returns the .sa5 bytes (np.uint8, 5n)."""
+def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=None, d_text=None, return_device=False):
+    """Whole run on one GPU.  Returns the .sa5 bytes (np.uint8, 5n), or the device buffer holding them.
+    A sorter may return device-resident results ({"device": True, "psa_lo", "bwt", "gt_begin": DeviceBuffers,
+    "i0", "size"}), e.g. psascan_amd.extras.sort_halfblock for the full-size property tests."""
     text = np.ascontiguousarray(text, np.uint8)
     n = len(text)
     if n == 0:
         return np.zeros(0, np.uint8)
     tb = text.tobytes()
-    d_text = api.upload(text, pad_to=16)
+    if d_text is None:
+        d_text = api.upload(text, pad_to=16)
+    host_sorter = not getattr(sorter, "device", False)
     gt_words = (n + 31) // 32 + 2
     gt_cur = api.zeros(4 * gt_words)   # gt w.r.t. current block begin; bit idx = n - j
     gt_new = api.zeros(4 * gt_words)
     half_blocks = []
     keep = []
 
+    def dev(res, key, pad):
+        """device buffer of a sorter result field (uploads host arrays)"""
+        if res.get("device"):
+            return res[key]
+        a = np.asarray(res[key], np.uint8)
+        return api.upload(a[: (res["_bits"] + 7) // 8] if key == "gt_begin" else a, pad_to=pad)
+
+    def host_psa(res):
+        if res.get("device"):
+            return api.download(res["psa_lo"], np.uint32, res["size"])
+        return res["psa"]
+
     def up_hb(beg, res):
+        if res.get("device"):
+            return {"beg": beg, "size": res["size"], "psa_lo": res["psa_lo"], "psa_hi": None, "mbv": None}
         psa = np.asarray(res["psa"], np.uint64)
         d_lo = api.upload((psa & np.uint64(0xFFFFFFFF)).astype(np.uint32))
         d_hi = api.upload((psa >> np.uint64(32)).astype(np.uint8)) if len(psa) and int(psa.max()) >> 32 else None
@@ -91,7 +109,7 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         last_block = e == n
         api.lib().psg_memset(gt_new.ptr, 0, gt_new.nbytes)
         # host copy of the tail gt (w.r.t. e) for the sorter: positions j in (e, e+rs]
-        cur_host = api.download(gt_cur, np.uint8, 4 * gt_words) if not last_block else None
+        cur_host = api.download(gt_cur, np.uint8, 4 * gt_words) if (not last_block and host_sorter) else None
 
         def gt_tail_e(v, cur_host=cur_host, e=e):
             j = e + v
@@ -103,9 +121,10 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         R = None
         if rs > 0:
             R = sorter(text, mid, e, gt_tail_e)
-            d_rbwt = api.upload(R["bwt"], pad_to=16)
-            d_rgt = api.upload(np.asarray(R["gt_begin"], np.uint8)[: (rs + 7) // 8], pad_to=8)
-            rgt_host = np.asarray(R["gt_begin"], np.uint8)
+            R["_bits"] = rs
+            d_rbwt = dev(R, "bwt", 16)
+            d_rgt = dev(R, "gt_begin", 8)
+            rgt_host = np.asarray(R["gt_begin"], np.uint8) if host_sorter else None
 
             def gt_tail_mid(v, rgt_host=rgt_host, e=e, mid=mid):
                 j = mid + v            # j in (mid, e]: right half's gt_begin, u = e - j
@@ -114,7 +133,8 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         else:
             gt_tail_mid = gt_tail_e
         L = sorter(text, b, mid, gt_tail_mid)
-        d_lgt = api.upload(np.asarray(L["gt_begin"], np.uint8)[: (ls + 7) // 8], pad_to=8)
+        L["_bits"] = ls
+        d_lgt = dev(L, "gt_begin", 8)
         hbL = up_hb(b, L)
         if rs == 0:
             api.bitcopy(gt_new, n - mid, d_lgt, 0, ls)
@@ -122,12 +142,12 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
             gt_cur, gt_new = gt_new, gt_cur
             continue
         hbR = up_hb(mid, R)
-        d_lbwt = api.upload(L["bwt"], pad_to=16)
+        d_lbwt = dev(L, "bwt", 16)
         # ---- step 3: pass A, right half streamed through rank(left BWT) (:403-414)
         rankL = api.rank_build(d_lbwt, ls)
         gapA = api.zeros(4 * (ls + 2))
         gtA = api.zeros(4 * ((rs + 31) // 32 + 1))
-        initA = rank_by_search(tb, b, L["psa"], e)
+        initA = rank_by_search(tb, b, host_psa(L), e)
         _, stA = api.stream_gap(rankL, L["i0"], text[mid - 1], d_text.at(mid), rs, d_rgt, initA, gapA, gtA, max_chains)
         rankL.free()
         if stats is not None:
@@ -169,6 +189,8 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
     half_blocks.sort(key=lambda h: h["beg"])       # merge.hpp:59
     half_blocks[-1]["mbv"] = None
     d_out = api.merge_half_blocks(half_blocks)
+    if return_device:
+        return d_out
     out = api.download(d_out, np.uint8, 5 * n)
     keep.clear()
     return out
