@@ -1,0 +1,186 @@
+// rank_sm.hpp -- "symbol-major" rank layout: ONE 16-byte load per query for general alphabets.
+// (included by rank_stream.hip)
+//
+// The interleaved-block layout needs two HBM sectors per query (counter sector + data sector) and
+// MI355X serves ~51 G random sectors/s (profiles/r01_membench.txt), so the stream kernel saturates
+// at ~22 G steps/s.  Here every symbol c owns an array E_c of 16-byte entries, one per BUCKET of
+// the BWT, that holds the running count AND the positions of c inside the bucket:
+//   LIST   (rare symbols, bucket = 256 positions):
+//            word0 = #c before the bucket ; byte4 = n ; bytes 5..15 = positions (0xFF = unused)
+//            n > 11  ->  byte4 = 0xFF, word2 = index of a 256-bit bitmap in the overflow pool
+//   BITMAP (frequent symbols, bucket = 64 positions):
+//            word0 = #c before the bucket ; words 2,3 = 64-bit occupancy bitmap
+// rank(i, c) = word0 + #positions < (i mod bucket): one sector.  Space = 16 B x (m/256 | m/64) per
+// symbol: 16 B/symbol of text for a uniform byte alphabet (the block layout with B=32 needs 33).
+// Semantics are those of rank4n<>::rank (rank.hpp:566-568).
+#pragma once
+
+#define SM_ABSENT 0u
+#define SM_LIST 1u
+#define SM_BITMAP 2u
+#define SM_MODE_SHIFT 62
+#define SM_OFF_MASK ((1ull << SM_MODE_SHIFT) - 1ull)
+#define SM_SEG 4096          // positions per build segment (= seg_hist_kernel<256,64> granularity)
+#define SM_CAP 11            // positions that fit into a LIST entry
+
+// t2 = per-symbol descriptor (offset of E_c in 16-byte units | mode << 62), i in (0, m)
+__device__ __forceinline__ u32 sm_rank(const u8 *entries, const u8 *pool, u64 t2, i64 i, u32 c) {
+  (void)c;
+  const uint4 *E = (const uint4 *)entries + (t2 & SM_OFF_MASK);
+  if ((u32)(t2 >> SM_MODE_SHIFT) == SM_BITMAP) {
+    uint4 e = E[i >> 6];
+    u32 off = (u32)i & 63u;
+    u64 bm = (u64)e.z | ((u64)e.w << 32);
+    return e.x + (u32)__popcll(bm & ((1ull << off) - 1ull));
+  }
+  uint4 e = E[i >> 8];
+  u32 off = (u32)i & 255u;
+  u32 n = e.y & 255u;
+  if (n != 0xFFu) {   // unused slots hold 0xFF, which is never < off (off <= 255)
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) cnt += ((e.y >> (8 * j)) & 255u) < off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cnt += ((e.z >> (8 * j)) & 255u) < off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cnt += ((e.w >> (8 * j)) & 255u) < off;
+    return e.x + cnt;
+  }
+  const uint4 *bp = (const uint4 *)(pool + (size_t)e.z * 32);
+  uint4 a = bp[0], b = bp[1];
+  u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32 cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int rem = (int)off - 32 * k;
+    u32 mask = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    cnt += __popc(w[k] & mask);
+  }
+  return e.x + cnt;
+}
+
+// bit k of the result = (byte k of the 4-byte word == c)
+__device__ __forceinline__ u32 sm_eq_nibble(u32 w, u32 c4) {
+  u32 y = (swar_eq_mask(w, c4) >> 7) & 0x01010101u;
+  return (y & 1u) | ((y >> 7) & 2u) | ((y >> 14) & 4u) | ((y >> 21) & 8u);
+}
+
+#define SM_MAX_BITMAP 32     // symbols that may use BITMAP mode (LDS budget of the fill kernel)
+
+// One workgroup per segment of 4096 positions.  Entries are assembled in LDS and written out with
+// neighbouring lanes covering neighbouring entries of the same symbol (128-byte / 1-KiB runs):
+// a thread-per-symbol store pattern would issue 2 G fully divergent 16-byte stores for a 2 GiB BWT.
+struct SmListLds {                               // LIST phase (per half segment = 8 buckets of 256)
+  u32 cnt[8 * 256];
+  u8 pos[8 * 256 * SM_CAP];
+  uint4 out[256 * 8];                            // entry (symbol c, bucket j) at c*8 + j
+};
+struct SmBitmapLds {                             // BITMAP phase (64 sub-buckets of 64)
+  u64 bm[SM_MAX_BITMAP * 64];
+  u32 cum[SM_MAX_BITMAP * 64];
+};
+union SmPhaseLds { SmListLds L; SmBitmapLds B; };
+
+__global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, const u64 *t2g, const u32 *seg_pref, const u64 *group_base,
+                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err) {
+  __shared__ __attribute__((aligned(16))) u8 sym[SM_SEG];
+  __shared__ __attribute__((aligned(16))) SmPhaseLds P;
+  __shared__ u64 t2S[256];
+  __shared__ u8 bmSym[SM_MAX_BITMAP];            // symbols in BITMAP mode
+  __shared__ int nbm;
+  const int c = threadIdx.x;
+  const i64 seg = blockIdx.x, base = seg * SM_SEG;
+  const u64 t2 = t2g[c];
+  const u32 mymode = (u32)(t2 >> SM_MODE_SHIFT);
+  t2S[c] = t2;
+  if (c == 0) nbm = 0;
+  if (base + SM_SEG <= m && ((uintptr_t)bwt & 15) == 0) {
+    ((uint4 *)sym)[c] = ((const uint4 *)(bwt + base))[c];
+  } else {
+    for (int k = c; k < SM_SEG; k += 256) sym[k] = base + k < m ? bwt[base + k] : 0;
+  }
+  __syncthreads();
+  if (mymode == SM_BITMAP) { int k = atomicAdd(&nbm, 1); if (k < SM_MAX_BITMAP) bmSym[k] = (u8)c; }
+  u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c]);
+  const u32 c4 = (u32)c * 0x01010101u;
+  // ---------------- LIST symbols: two halves of 8 buckets ----------------
+  for (int half = 0; half < 2; ++half) {
+    for (int k = c; k < 8 * 256; k += 256) P.L.cnt[k] = 0;
+    for (int k = c; k < 8 * 256 * SM_CAP / 4; k += 256) ((u32 *)P.L.pos)[k] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int j = 0; j < 8; ++j) {
+      int q = (half * 8 + j) * 256 + c;
+      if (base + q < m) {
+        u32 s = sym[q];
+        if ((u32)(t2S[s] >> SM_MODE_SHIFT) == SM_LIST) {
+          u32 slot = atomicAdd(&P.L.cnt[j * 256 + s], 1u);
+          if (slot < SM_CAP) P.L.pos[(j * 256 + s) * SM_CAP + slot] = (u8)c;   // position inside the bucket = c
+        }
+      }
+    }
+    __syncthreads();
+    if (mymode == SM_LIST) {
+      for (int j = 0; j < 8; ++j) {
+        u32 n = P.L.cnt[j * 256 + c];
+        uint4 e;
+        e.x = run;
+        if (n <= SM_CAP) {
+          const u8 *p = P.L.pos + (j * 256 + c) * SM_CAP;
+          e.y = n | ((u32)p[0] << 8) | ((u32)p[1] << 16) | ((u32)p[2] << 24);
+          e.z = (u32)p[3] | ((u32)p[4] << 8) | ((u32)p[5] << 16) | ((u32)p[6] << 24);
+          e.w = (u32)p[7] | ((u32)p[8] << 8) | ((u32)p[9] << 16) | ((u32)p[10] << 24);
+        } else {   // dense bucket: 256-bit bitmap in the overflow pool
+          u32 idx = atomicAdd(pool_cursor, 1u);
+          e.y = 0xFFu; e.z = idx; e.w = 0;
+          if (idx < pool_cap) {
+            const u8 *bs = sym + (half * 8 + j) * 256;
+            i64 lim = m - (base + (half * 8 + j) * 256);
+            for (int k = 0; k < 8; ++k) {
+              u32 bits = 0;
+              for (int w = 0; w < 8; ++w) bits |= sm_eq_nibble(((const u32 *)bs)[k * 8 + w], c4) << (4 * w);
+              int rem = (int)std::min<i64>(lim - 32 * k, 32);
+              if (rem < 32) bits &= rem <= 0 ? 0u : ((1u << rem) - 1u);
+              pool[(size_t)idx * 8 + k] = bits;
+            }
+          } else *err = 1;
+        }
+        P.L.out[c * 8 + j] = e;
+        run += n;
+      }
+    }
+    __syncthreads();
+    for (int idx = c; idx < 256 * 8; idx += 256) {   // lanes 8k..8k+7 write 128 contiguous bytes of one symbol
+      int s = idx >> 3, j = idx & 7;
+      u64 ts = t2S[s];
+      i64 bk = seg * 16 + half * 8 + j;
+      if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST && bk * 256 < m) entries[(ts & SM_OFF_MASK) + bk] = P.L.out[idx];
+    }
+    __syncthreads();
+  }
+  // ---------------- BITMAP symbols: (symbol, sub-bucket) items ----------------
+  const int nb = nbm < SM_MAX_BITMAP ? nbm : SM_MAX_BITMAP;
+  for (int item = c; item < nb * 64; item += 256) {
+    int s = bmSym[item >> 6], sub = item & 63;
+    const u32 *ws = (const u32 *)(sym + sub * 64);
+    u32 s4 = (u32)s * 0x01010101u;
+    u64 bm = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) bm |= (u64)sm_eq_nibble(ws[w], s4) << (4 * w);
+    i64 lim = m - (base + sub * 64);
+    if (lim < 64) bm &= lim <= 0 ? 0ull : ((1ull << lim) - 1ull);
+    P.B.bm[item] = bm;
+  }
+  __syncthreads();
+  if (mymode == SM_BITMAP) {   // running counts over the 64 sub-buckets of this symbol
+    int k = 0;
+    while (k < nb && bmSym[k] != c) ++k;
+    if (k < nb) for (int sub = 0; sub < 64; ++sub) { P.B.cum[k * 64 + sub] = run; run += (u32)__popcll(P.B.bm[k * 64 + sub]); }
+  }
+  __syncthreads();
+  for (int item = c; item < nb * 64; item += 256) {
+    int s = bmSym[item >> 6], sub = item & 63;
+    i64 bk = seg * (SM_SEG / 64) + sub;
+    u64 bm = P.B.bm[item];
+    if (bk * 64 < m) entries[(t2S[s] & SM_OFF_MASK) + bk] = make_uint4(P.B.cum[item], 0u, (u32)bm, (u32)(bm >> 32));
+  }
+}

@@ -37,6 +37,8 @@ struct psg_rank {
   i64 blocks_bytes = 0;
   u64 *d_sb = nullptr;            // [nsb][cnt]
   std::vector<u64> h_sb;          // host copy
+  u8 *d_aux = nullptr;            // symbol-major layout: overflow pool
+  u64 t2[256] = {0};              // symbol-major layout: per-symbol descriptor (offset/16 | mode << 62)
   u8 code[256];                   // symbol -> code (0xFF = absent)
   i64 count[256];                 // occurrences per symbol (m_count, rank.hpp:112)
 };
@@ -116,12 +118,15 @@ template <int B, int MID> __device__ __forceinline__ u32 count_two(const u8 *dat
   return acc;
 }
 
-template <int CNT, int B> struct RankView {
+template <int CNT, int B> struct RankView {   // CNT == 0: symbol-major layout (rank_sm.hpp)
   const u8 *blocks;
   i64 m;
+  const u8 *aux;                                     // symbol-major layout: overflow bitmap pool
   static constexpr int STRIDE = 4 * CNT + B;
   static constexpr int MID = B == 48 ? 32 : B / 2;   // multiple of 16, >= B - MID
 };
+
+#include "rank_sm.hpp"
 
 // One LF step: returns C[c] + rank(i, c) (before the delta / gt corrections).
 // T1: LDS table [nsb][256] of  (C[c] + superblock base) | code << 56 ; tot: LDS [256].
@@ -132,6 +137,11 @@ __device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1,
   i64 Cc = (i64)(e0 & VAL_MASK);
   if (i <= 0) return Cc;
   if (i >= R.m) return Cc + (i64)tot[c];
+  if constexpr (CNT == 0) {   // symbol-major: one 16-byte load (descriptors live behind tot[] in LDS)
+    u64 t2 = tot[256 + c];
+    if ((u32)(t2 >> SM_MODE_SHIFT) == SM_ABSENT) return Cc;
+    return Cc + (i64)sm_rank(R.blocks, R.aux, t2, i, c);
+  } else {
   if (CNT < 256 && code == 0xFFu) return Cc;
   i64 blk = i / B;
   int off = (int)(i - blk * B);
@@ -146,6 +156,7 @@ __device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1,
   i64 sb = blk >> SB_SHIFT;
   i64 base = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
   return base + ctr + (upper ? (i64)cnt : -(i64)cnt);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
 // LDS table loader shared by the query / warm-up / stream kernels
 __device__ __forceinline__ void load_tables(u64 *lds, const u64 *g_T1, const u64 *g_tot, int nsb) {
   for (int k = threadIdx.x; k < nsb * 256; k += blockDim.x) lds[k] = g_T1[k];
-  for (int k = threadIdx.x; k < 256; k += blockDim.x) lds[nsb * 256 + k] = g_tot[k];
+  for (int k = threadIdx.x; k < 512; k += blockDim.x) lds[nsb * 256 + k] = g_tot[k];   // tot[256] + symbol-major descriptors[256]
   __syncthreads();
 }
 
@@ -461,7 +472,8 @@ __global__ __launch_bounds__(PSG_WG) void warmup_kernel(RankView<CNT, B> R, Warm
 // ---------------------------------------------------------------------------------------
 #define DISPATCH_LAYOUT(r, F, ...)                                                                   \
   do {                                                                                               \
-    if ((r)->cnt == 4 && (r)->B == 48) { F<4, 48>(__VA_ARGS__); }                                    \
+    if ((r)->cnt == 0) { F<0, 0>(__VA_ARGS__); }                                                     \
+    else if ((r)->cnt == 4 && (r)->B == 48) { F<4, 48>(__VA_ARGS__); }                               \
     else if ((r)->cnt == 16 && (r)->B == 64) { F<16, 64>(__VA_ARGS__); }                             \
     else if ((r)->cnt == 256 && (r)->B == 32) { F<256, 32>(__VA_ARGS__); }                           \
     else if ((r)->cnt == 256 && (r)->B == 64) { F<256, 64>(__VA_ARGS__); }                           \
@@ -478,6 +490,61 @@ static void launch_build(const u8 *d_bwt, i64 m, const u8 *d_code, u32 *seg_cnt,
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum, ngroups, CNT);
   hipLaunchKernelGGL((rank_fill_kernel<CNT, B>), dim3((unsigned)r->nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, d_code, seg_cnt,
                      group_sum, r->d_blocks, r->nblk);
+}
+
+// Symbol-major layout (rank_sm.hpp).  *fell_back = true: not applicable / did not fit / overflow
+// pool exhausted -- the caller builds a block layout instead.
+static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double budget_bytes, bool *fell_back) {
+  *fell_back = true;
+  if (m >= 0xFFFFFFFFll) return 0;
+  // per-symbol mode: BITMAP (bucket 64) when a 256-bucket would hold > 3 occurrences on average
+  u64 off16 = 0;
+  u64 t2[256];
+  int nbitmap = 0;
+  for (int c = 0; c < 256; ++c) nbitmap += h[c] && (double)h[c] * 256.0 > 3.0 * (double)m;
+  if (nbitmap > SM_MAX_BITMAP) return 0;   // too many frequent symbols for the fill kernel's LDS budget
+  for (int c = 0; c < 256; ++c) {
+    if (!h[c]) { t2[c] = 0; continue; }
+    bool bitmap = (double)h[c] * 256.0 > 3.0 * (double)m;
+    u64 nbk = bitmap ? (u64)cdiv(m, 64) : (u64)cdiv(m, 256);
+    t2[c] = off16 | ((u64)(bitmap ? SM_BITMAP : SM_LIST) << SM_MODE_SHIFT);
+    off16 += nbk;
+  }
+  const i64 entries_bytes = (i64)off16 * 16;
+  const u32 pool_cap = (u32)std::max<i64>(1024, m / 512);   // 32-byte bitmaps for dense LIST buckets
+  if ((double)entries_bytes + 32.0 * pool_cap > budget_bytes) return 0;
+  const i64 nseg = cdiv(m, SM_SEG), ngroups = cdiv(nseg, GROUP_SEGS);
+  DevBuf code_d, seg_cnt, group_sum, t2_d, misc;
+  int rc;
+  u8 ident[256];
+  for (int c = 0; c < 256; ++c) ident[c] = (u8)c;
+  u8 *entries = nullptr, *pool = nullptr;
+  if (psg::pool_alloc((void **)&entries, (size_t)entries_bytes + 64) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (psg::pool_alloc((void **)&pool, (size_t)pool_cap * 32) != hipSuccess) { (void)hipGetLastError(); psg::pool_free(entries); return 0; }
+  auto fail = [&](int code) { psg::pool_free(entries); psg::pool_free(pool); return code; };
+  if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(nseg * 256 * 4)) || (rc = group_sum.alloc(ngroups * 256 * 8)) || (rc = t2_d.alloc(256 * 8)) || (rc = misc.alloc(8)))
+    return fail(rc);
+  hipError_t e1 = hipMemcpyAsync(code_d.p, ident, 256, hipMemcpyHostToDevice, stream());
+  hipError_t e2 = hipMemcpyAsync(t2_d.p, t2, sizeof t2, hipMemcpyHostToDevice, stream());
+  hipError_t e3 = hipMemsetAsync(misc.p, 0, 8, stream());
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("sm_build: copy failed"); return fail(PSG_EDEVICE); }
+  hipLaunchKernelGGL((seg_hist_kernel<256, 64>), dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>());
+  hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * 256, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt.as<u32>(), nseg, 256, group_sum.as<u64>(), ngroups);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
+  hipLaunchKernelGGL(sm_fill_kernel, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
+                     (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
+  u32 st[2] = {0, 0};
+  hipError_t e4 = hipGetLastError();
+  hipError_t e5 = hipMemcpyAsync(st, misc.p, 8, hipMemcpyDeviceToHost, stream());
+  hipError_t e6 = hipStreamSynchronize(stream());
+  if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4 != hipSuccess ? e4 : e6)); return fail(PSG_EDEVICE); }
+  if (st[1] || st[0] > pool_cap) { psg::pool_free(entries); psg::pool_free(pool); return 0; }   // too many dense buckets: block layout instead
+  r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = 1;
+  r->d_blocks = entries; r->d_aux = pool; r->blocks_bytes = entries_bytes + (i64)pool_cap * 32;
+  for (int c = 0; c < 256; ++c) { r->t2[c] = t2[c]; r->code[c] = (u8)c; }
+  r->h_sb.assign(1, 0);
+  *fell_back = false;
+  return 0;
 }
 
 extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, psg_rank_t **out) {
@@ -501,6 +568,27 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   r->m = m;
   int sigma = 0;
   for (int c = 0; c < 256; ++c) { r->count[c] = (i64)h[c]; sigma += h[c] != 0; }
+  {
+    // symbol-major layout (one sector per query): general alphabets by default, or forced with
+    // data_bytes_per_block == 1 / PSG_RANK_LAYOUT=sm; PSG_RANK_LAYOUT=block disables it.
+    const char *env = getenv("PSG_RANK_LAYOUT");
+    bool want_sm = data_bytes == 1 || (env && !strcmp(env, "sm") && data_bytes == 0) || (data_bytes == 0 && sigma > 16 && !(env && !strcmp(env, "block")));
+    if (want_sm) {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      bool fell_back = true;
+      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), &fell_back);
+      if (rc) { delete r; return rc; }
+      if (!fell_back) {
+        tm.stop();
+        PSG_HIP(hipStreamSynchronize(stream()));
+        note_kernel_ms(tm.ms());
+        *out = r;
+        return 0;
+      }
+      if (data_bytes == 1) data_bytes = 0;   // forced but not applicable: block layout
+    }
+  }
   if (data_bytes == 0) {
     if (sigma <= 4) { r->cnt = 4; r->B = 48; }
     else if (sigma <= 16) { r->cnt = 16; r->B = 64; }
@@ -533,7 +621,12 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
   PSG_HIP(hipMemcpyAsync(code_d.p, r->code, 256, hipMemcpyHostToDevice, stream()));
-  DISPATCH_LAYOUT(r, launch_build, d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  if (r->cnt == 4) launch_build<4, 48>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  else if (r->cnt == 16) launch_build<16, 64>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  else if (r->B == 32) launch_build<256, 32>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  else if (r->B == 64) launch_build<256, 64>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  else if (r->B == 128) launch_build<256, 128>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
+  else launch_build<256, 256>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
   PSG_HIP(hipGetLastError());
   // superblock bases = group bases at the superblock starts
   r->h_sb.assign((size_t)r->nsb * r->cnt, 0);
@@ -551,6 +644,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
 extern "C" void psg_rank_free(psg_rank_t *r) {
   if (!r) return;
   if (r->d_blocks) psg::pool_free(r->d_blocks);
+  if (r->d_aux) psg::pool_free(r->d_aux);
   delete r;
 }
 extern "C" int psg_rank_counts(const psg_rank_t *r, int64_t counts[256]) {
@@ -562,26 +656,26 @@ extern "C" int64_t psg_rank_device_bytes(const psg_rank_t *r) { return r ? r->bl
 
 // T1[sb][c] = (Cadd[c] + sb_base[sb][code[c]]) | code << 56 ; tot[c] = count[c]
 static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &tot) {
-  std::vector<u64> h((size_t)r->nsb * 256), t(256);
+  std::vector<u64> h((size_t)r->nsb * 256), t(512, 0);
   for (int s = 0; s < r->nsb; ++s)
     for (int c = 0; c < 256; ++c) {
       u8 cd = r->code[c];
-      u64 base = cd == 0xFF ? 0 : r->h_sb[(size_t)s * r->cnt + cd];
+      u64 base = (cd == 0xFF || r->cnt == 0) ? 0 : r->h_sb[(size_t)s * r->cnt + cd];
       h[(size_t)s * 256 + c] = ((u64)(Cadd ? Cadd[c] : 0) + base) | ((u64)cd << CODE_SHIFT);
     }
-  for (int c = 0; c < 256; ++c) t[c] = (u64)r->count[c];
+  for (int c = 0; c < 256; ++c) { t[c] = (u64)r->count[c]; t[256 + c] = r->t2[c]; }
   if (int rc = T1.alloc((i64)h.size() * 8)) return rc;
-  if (int rc = tot.alloc(256 * 8)) return rc;
+  if (int rc = tot.alloc(512 * 8)) return rc;
   PSG_HIP(hipMemcpyAsync(T1.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream()));
-  PSG_HIP(hipMemcpyAsync(tot.p, t.data(), 256 * 8, hipMemcpyHostToDevice, stream()));
+  PSG_HIP(hipMemcpyAsync(tot.p, t.data(), 512 * 8, hipMemcpyHostToDevice, stream()));
   PSG_HIP(hipStreamSynchronize(stream()));  // h, t go out of scope
   return 0;
 }
 
 template <int CNT, int B>
 static void launch_query(const psg_rank *r, const u64 *T1, const u64 *tot, const i64 *qi, const u8 *qc, i64 nq, i64 *out) {
-  RankView<CNT, B> R{r->d_blocks, r->m};
-  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((rank_query_kernel<CNT, B>), dim3((unsigned)cdiv(nq, PSG_WG)), dim3(PSG_WG), lds, stream(), R, T1, tot,
                      r->nsb, qi, qc, nq, out);
 }
@@ -598,13 +692,13 @@ extern "C" int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uin
 }
 
 template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams P) {
-  RankView<CNT, B> R{r->d_blocks, r->m};
-  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
 }
 template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode) {
-  RankView<CNT, B> R{r->d_blocks, r->m};
-  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   dim3 grid((unsigned)cdiv(P.nchains, PSG_WG));
   if (mode == 2) hipLaunchKernelGGL((stream_kernel<CNT, B, 2>), grid, dim3(PSG_WG), lds, stream(), R, P);
   else if (mode == 1) hipLaunchKernelGGL((stream_kernel<CNT, B, 1>), grid, dim3(PSG_WG), lds, stream(), R, P);
@@ -613,7 +707,7 @@ template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamPar
 
 // resident workgroups per CU of the stream kernel that will be launched (occupancy API)
 template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int *blocks) {
-  size_t lds = ((size_t)r->nsb * 256 + 256) * 8;
+  size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   *blocks = 0;
   if (mode == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 2>, PSG_WG, lds);
   else if (mode == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 1>, PSG_WG, lds);

@@ -47,12 +47,19 @@ KINDS = ["rand255", "sig4z", "dna", "sig12", "alla", "fib", "per3", "zeros"]
 
 
 # ------------------------------------------------------------------ rank (a3)
-@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 32), (255, 64), (255, 128), (255, 256), (4, 0), (4, -64), (12, 0),
-                                          (2, 0), (1, 0)])
+@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 1), (255, 32), (255, 64), (255, 128), (255, 256), (4, 0), (4, 1), (4, -64),
+                                          (12, 0), (12, 1), (2, 0), (1, 0), (1, 1), ("runs", 1), ("skew", 1)])
 @pytest.mark.parametrize("m", [1, 47, 48, 49, 64, 4095, 4096, 4097, 100003])
 def test_rank_query(A, sigma, layout, m):
-    rng = np.random.default_rng(m * 7 + sigma)
-    bwt = rng.integers(0, sigma, m, dtype=np.uint8)
+    rng = np.random.default_rng(m * 7 + (sigma if isinstance(sigma, int) else 5))
+    if sigma == "runs":       # BWT-like: runs of one symbol -> dense buckets of rare symbols (overflow pool of the symbol-major layout)
+        bwt = np.repeat(rng.integers(0, 200, m // 20 + 1, dtype=np.uint8), rng.integers(1, 60, m // 20 + 1))[:m]
+        if len(bwt) < m:
+            bwt = np.concatenate([bwt, np.zeros(m - len(bwt), np.uint8)])
+    elif sigma == "skew":     # a few frequent symbols (bitmap mode) among many rare ones (list mode)
+        bwt = np.where(rng.random(m) < 0.8, rng.integers(0, 3, m), rng.integers(3, 250, m)).astype(np.uint8)
+    else:
+        bwt = rng.integers(0, sigma, m, dtype=np.uint8)
     if sigma == 12:
         bwt = bwt * 20 + 3
     r = A.rank_build(A.upload(bwt, pad_to=16), m, layout)
