@@ -23,18 +23,12 @@
 #define SM_SEG 4096          // positions per build segment (= seg_hist_kernel<256,64> granularity)
 #define SM_CAP 11            // positions that fit into a LIST entry
 
-// t2 = per-symbol descriptor (offset of E_c in 16-byte units | mode << 62), i in (0, m)
-__device__ __forceinline__ u32 sm_rank(const u8 *entries, const u8 *pool, u64 t2, i64 i, u32 c) {
-  (void)c;
-  const uint4 *E = (const uint4 *)entries + (t2 & SM_OFF_MASK);
+// rank inside a loaded entry: e = E_c[bucket], off = i mod bucket size, t2 = descriptor of the symbol
+__device__ __forceinline__ u32 sm_rank_entry(const uint4 &e, const u8 *pool, u64 t2, u32 off) {
   if ((u32)(t2 >> SM_MODE_SHIFT) == SM_BITMAP) {
-    uint4 e = E[i >> 6];
-    u32 off = (u32)i & 63u;
     u64 bm = (u64)e.z | ((u64)e.w << 32);
     return e.x + (u32)__popcll(bm & ((1ull << off) - 1ull));
   }
-  uint4 e = E[i >> 8];
-  u32 off = (u32)i & 255u;
   u32 n = e.y & 255u;
   if (n != 0xFFu) {   // unused slots hold 0xFF, which is never < off (off <= 255)
     u32 cnt = 0;
@@ -46,7 +40,7 @@ __device__ __forceinline__ u32 sm_rank(const u8 *entries, const u8 *pool, u64 t2
     for (int j = 0; j < 4; ++j) cnt += ((e.w >> (8 * j)) & 255u) < off;
     return e.x + cnt;
   }
-  const uint4 *bp = (const uint4 *)(pool + (size_t)e.z * 32);
+  const uint4 *bp = (const uint4 *)(pool + (size_t)e.z * 32);   // dense bucket: 256-bit bitmap in the pool
   uint4 a = bp[0], b = bp[1];
   u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   u32 cnt = 0;

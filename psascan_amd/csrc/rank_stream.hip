@@ -128,35 +128,81 @@ template <int CNT, int B> struct RankView {   // CNT == 0: symbol-major layout (
 
 #include "rank_sm.hpp"
 
-// One LF step: returns C[c] + rank(i, c) (before the delta / gt corrections).
-// T1: LDS table [nsb][256] of  (C[c] + superblock base) | code << 56 ; tot: LDS [256].
+// One LF step = C[c] + rank(i, c) (before the delta / gt corrections), split in two halves so that a
+// lane can have the loads of SEVERAL chains in flight before it needs any of the data:
+//   rank_issue  : LDS lookups, address computation, issue of the global loads
+//   rank_finish : arithmetic on the loaded registers
+// T1: LDS table [nsb][256] of (C[c] + superblock base) | code << 56 ; tot: LDS [256] (+ [256] descriptors).
+template <int CNT, int B> struct RankReq {
+  i64 res;       // kind == 0: the result; kind == 1: C[c] (+ superblock base)
+  u32 kind;
+  // symbol-major
+  u64 t2;
+  u32 off;
+  uint4 e;
+  // interleaved blocks
+  u32 ctr;
+  int lo, hi;
+  bool upper;
+  uint4 d[CNT == 0 ? 1 : RankView<CNT, B>::MID / 16];
+};
+
 template <int CNT, int B>
-__device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c) {
+__device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c, RankReq<CNT, B> &q) {
   u64 e0 = T1[c];
   u32 code = (u32)(e0 >> CODE_SHIFT);
   i64 Cc = (i64)(e0 & VAL_MASK);
-  if (i <= 0) return Cc;
-  if (i >= R.m) return Cc + (i64)tot[c];
+  q.kind = 0;
+  q.res = Cc;
+  if (i <= 0) return;
+  if (i >= R.m) { q.res = Cc + (i64)tot[c]; return; }
   if constexpr (CNT == 0) {   // symbol-major: one 16-byte load (descriptors live behind tot[] in LDS)
     u64 t2 = tot[256 + c];
-    if ((u32)(t2 >> SM_MODE_SHIFT) == SM_ABSENT) return Cc;
-    return Cc + (i64)sm_rank(R.blocks, R.aux, t2, i, c);
+    u32 mode = (u32)(t2 >> SM_MODE_SHIFT);
+    if (mode == SM_ABSENT) return;
+    const uint4 *E = (const uint4 *)R.blocks + (t2 & SM_OFF_MASK);
+    bool bm = mode == SM_BITMAP;
+    q.e = E[bm ? (i >> 6) : (i >> 8)];
+    q.off = (u32)i & (bm ? 63u : 255u);
+    q.t2 = t2;
+    q.kind = 1;
   } else {
-  if (CNT < 256 && code == 0xFFu) return Cc;
-  i64 blk = i / B;
-  int off = (int)(i - blk * B);
-  const u8 *p = R.blocks + blk * (i64)RankView<CNT, B>::STRIDE;
-  constexpr int MID = RankView<CNT, B>::MID;
-  u32 ctr = *(const u32 *)(p + 4 * code);
-  bool upper = off >= MID;
-  i64 valid = R.m - blk * B;                       // symbols stored in this block (last block may be short)
-  int lim = valid < MID ? (int)valid : MID;
-  int lo = upper ? 0 : off, hi = upper ? off - MID : lim;
-  u32 cnt = count_range<MID / 16>(p + 4 * CNT + (upper ? MID : 0), c, lo, hi);
-  i64 sb = blk >> SB_SHIFT;
-  i64 base = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
-  return base + ctr + (upper ? (i64)cnt : -(i64)cnt);
+    if (CNT < 256 && code == 0xFFu) return;
+    i64 blk = i / B;
+    int off = (int)(i - blk * B);
+    const u8 *p = R.blocks + blk * (i64)RankView<CNT, B>::STRIDE;
+    constexpr int MID = RankView<CNT, B>::MID;
+    q.ctr = *(const u32 *)(p + 4 * code);
+    q.upper = off >= MID;
+    i64 valid = R.m - blk * B;                     // symbols stored in this block (last block may be short)
+    int lim = valid < MID ? (int)valid : MID;
+    q.lo = q.upper ? 0 : off;
+    q.hi = q.upper ? off - MID : lim;
+    const uint4 *dp = (const uint4 *)(p + 4 * CNT + (q.upper ? MID : 0));
+#pragma unroll
+    for (int k = 0; k < MID / 16; ++k) q.d[k] = dp[k];
+    i64 sb = blk >> SB_SHIFT;
+    q.res = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
+    q.kind = 1;
   }
+}
+
+template <int CNT, int B>
+__device__ __forceinline__ i64 rank_finish(const RankView<CNT, B> &R, u32 c, const RankReq<CNT, B> &q) {
+  if (q.kind == 0) return q.res;
+  if constexpr (CNT == 0) {
+    return q.res + (i64)sm_rank_entry(q.e, R.aux, q.t2, q.off);
+  } else {
+    u32 cnt = count_range<RankView<CNT, B>::MID / 16>((const u8 *)q.d, c, q.lo, q.hi);
+    return q.res + q.ctr + (q.upper ? (i64)cnt : -(i64)cnt);
+  }
+}
+
+template <int CNT, int B>
+__device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c) {
+  RankReq<CNT, B> q;
+  rank_issue<CNT, B>(R, T1, tot, i, c, q);
+  return rank_finish<CNT, B>(R, c, q);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -335,88 +381,149 @@ struct StreamParams {
 };
 
 // MODE 0: atomicAdd on the gap counters; 1: same with u32 overflow detection;
-// MODE 2: no atomics -- the ranks are logged (coalesced: one dword per lane per step, 256 B per
-//         wave) and histogrammed afterwards (gap_hist.hip).
-template <int CNT, int B, int MODE>
+// MODE 2: no atomics -- the ranks are logged (coalesced dwordx4 stores) and histogrammed afterwards
+//         (gap_hist.hip).
+// CPL = chains per lane: the steps of CPL independent chains are interleaved so that a lane has CPL
+//       rank loads in flight (memory-level parallelism beyond what 8 waves per SIMD give).
+struct Chain {
+  i64 i, k, u0, u1, w;
+  u64 thi, tlo;
+  int tcnt;
+  const uint4 *cp;
+  uint4 nxt;
+  uintptr_t last_addr;
+  u32 gin, gin_next, gout;
+};
+
+template <int CNT, int B, int MODE, int CPL>
 __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
   constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
-  __shared__ u32 lstage[MODE == 2 ? 4 * PSG_WG : 1];
+  __shared__ u32 lstage[MODE == 2 ? CPL * 4 * PSG_WG : 1];
   load_tables(lds, P.g_T1, P.g_tot, P.nsb);
   const u64 *T1 = lds, *tot = lds + P.nsb * 256;
+  const i64 nlanes = (P.nchains + CPL - 1) / CPL;
   i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
-  if (gid >= P.nchains) return;
-  i64 k = P.list ? P.list[gid] : gid;
-  i64 u0 = P.ctx + k * P.L;
-  i64 u1 = std::min<i64>(u0 + P.L, P.T);
-  i64 i = P.init[k];
-  // text cursor: descending bytes starting at tail[T-1-u0], consumed from a 128-bit shift
-  // register (no dynamically indexed registers: hipcc would spill those to scratch memory and
-  // put a scratch load + vmcnt(0) on the per-step critical path)
-  uintptr_t addr = (uintptr_t)(P.tail + (P.T - 1 - u0));
-  uintptr_t last_addr = (uintptr_t)(P.tail + (P.T - u1));  // address of the last byte this chain needs
-  const uint4 *cp = (const uint4 *)(addr & ~(uintptr_t)15);
-  int tcnt = (int)(addr & 15) + 1;                         // bytes left in the current chunk
-  uint4 cur = *cp, nxt = cur;
-  if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
-  u64 tlo = (u64)cur.x | ((u64)cur.y << 32), thi = (u64)cur.z | ((u64)cur.w << 32);
-  {
-    int sh = (16 - tcnt) * 8;                              // bring byte (tcnt-1) of the chunk to the top
-    if (sh >= 64) { thi = tlo << (sh - 64); tlo = 0; }
-    else if (sh > 0) { thi = (thi << sh) | (tlo >> (64 - sh)); tlo <<= sh; }
+  if (gid >= nlanes) return;
+  Chain S[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    Chain &c = S[q];
+    i64 idx = gid + q * nlanes;
+    bool act = idx < P.nchains;
+    c.k = act ? (P.list ? P.list[idx] : idx) : -1;
+    c.u0 = act ? P.ctx + c.k * P.L : 0;
+    c.u1 = act ? std::min<i64>(c.u0 + P.L, P.T) : 0;
+    c.i = act ? P.init[c.k] : 0;
+    c.w = c.u0 >> 5;
+    c.gin = 0; c.gin_next = 0; c.gout = 0;
+    c.tcnt = 1; c.thi = 0; c.tlo = 0; c.cp = nullptr; c.last_addr = 0; c.nxt = make_uint4(0, 0, 0, 0);
+    if (act) {
+      // text cursor: descending bytes starting at tail[T-1-u0], consumed from a 128-bit shift
+      // register (no dynamically indexed registers: hipcc would spill those to scratch memory)
+      uintptr_t addr = (uintptr_t)(P.tail + (P.T - 1 - c.u0));
+      c.last_addr = (uintptr_t)(P.tail + (P.T - c.u1));   // address of the last byte this chain needs
+      c.cp = (const uint4 *)(addr & ~(uintptr_t)15);
+      c.tcnt = (int)(addr & 15) + 1;                       // bytes left in the current chunk
+      uint4 cur = *c.cp;
+      c.nxt = cur;
+      if ((uintptr_t)c.cp > c.last_addr) c.nxt = *(c.cp - 1);
+      c.tlo = (u64)cur.x | ((u64)cur.y << 32);
+      c.thi = (u64)cur.z | ((u64)cur.w << 32);
+      int sh = (16 - c.tcnt) * 8;                          // bring byte (tcnt-1) of the chunk to the top
+      if (sh >= 64) { c.thi = c.tlo << (sh - 64); c.tlo = 0; }
+      else if (sh > 0) { c.thi = (c.thi << sh) | (c.tlo >> (64 - sh)); c.tlo <<= sh; }
+      c.gin = P.gt_in ? P.gt_in[c.w] : 0u;
+    }
   }
-  i64 w = u0 >> 5;
   bool ovf = false;
-  u32 gin = P.gt_in ? P.gt_in[w] : 0u;
-  for (i64 u = u0; u < u1; u += 32, ++w) {
-    u32 gin_next = (P.gt_in && u + 32 < u1) ? P.gt_in[w + 1] : 0u;   // prefetch the next gt word
-    u32 gout = 0;
-    int steps = (int)std::min<i64>(32, u1 - u);
-    for (int t = 0; t < steps; ++t) {
-      u32 c = (u32)(thi >> 56);
-      thi = (thi << 8) | (tlo >> 56);
-      tlo <<= 8;
-      bool gt_i0 = i > P.i0;
-      gout |= (u32)gt_i0 << t;
-      i64 ni = lf_core<CNT, B>(R, T1, tot, i, c);
-      ni -= (gt_i0 && c == 0) ? 1 : 0;
-      ni += (c == P.last && ((gin >> t) & 1u)) ? 1 : 0;
-      i = ni;
-      if (MODE == 2) {
-        // 4 consecutive ranks of a chain leave as ONE dwordx4 store (memory instructions per step are
-        // the scarce resource of this kernel); lane-private LDS slots, no barrier needed
-        lstage[(t & 3) * PSG_WG + threadIdx.x] = (u32)i;
-        if ((t & 3) == 3) {
-          uint4 q4 = make_uint4(lstage[threadIdx.x], lstage[PSG_WG + threadIdx.x], lstage[2 * PSG_WG + threadIdx.x], lstage[3 * PSG_WG + threadIdx.x]);
-          ((uint4 *)P.log)[((u - u0 + t) >> 2) * P.K + k] = q4;
+  for (i64 g = 0; g < P.L; g += 32) {
+    int steps[CPL], smax = 0;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      Chain &c = S[q];
+      i64 rem = c.u1 - c.u0 - g;
+      steps[q] = rem <= 0 ? 0 : (rem < 32 ? (int)rem : 32);
+      smax = steps[q] > smax ? steps[q] : smax;
+      c.gin_next = (steps[q] && P.gt_in && c.u0 + g + 32 < c.u1) ? P.gt_in[c.w + 1] : 0u;   // prefetch the next gt word
+      c.gout = 0;
+    }
+    if (smax == 0) break;
+    for (int t = 0; t < smax; ++t) {
+      RankReq<CNT, B> req[CPL];
+      u32 sym[CPL];
+      bool gti0[CPL];
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if (t < steps[q]) {
+          Chain &c = S[q];
+          sym[q] = (u32)(c.thi >> 56);
+          c.thi = (c.thi << 8) | (c.tlo >> 56);
+          c.tlo <<= 8;
+          gti0[q] = c.i > P.i0;
+          c.gout |= (u32)gti0[q] << t;
+          rank_issue<CNT, B>(R, T1, tot, c.i, sym[q], req[q]);
         }
-      } else if (CHECK_OVF) {
-        u32 old = atomicAdd(&P.gap[i], 1u);
-        ovf |= (old == 0xFFFFFFFFu);
-      } else {
-        atomicAdd(&P.gap[i], 1u);
       }
-      if (--tcnt == 0) {
-        tcnt = 16;
-        tlo = (u64)nxt.x | ((u64)nxt.y << 32);
-        thi = (u64)nxt.z | ((u64)nxt.w << 32);
-        --cp;
-        if ((uintptr_t)cp > last_addr) nxt = *(cp - 1);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if (t < steps[q]) {
+          Chain &c = S[q];
+          i64 ni = rank_finish<CNT, B>(R, sym[q], req[q]);
+          ni -= (gti0[q] && sym[q] == 0) ? 1 : 0;
+          ni += (sym[q] == P.last && ((c.gin >> t) & 1u)) ? 1 : 0;
+          c.i = ni;
+          if (MODE == 2) {
+            // 4 consecutive ranks of a chain leave as ONE dwordx4 store (memory instructions per step
+            // are the scarce resource of this kernel); lane-private LDS slots, no barrier needed
+            u32 *ls = lstage + q * 4 * PSG_WG;
+            ls[(t & 3) * PSG_WG + threadIdx.x] = (u32)ni;
+            if ((t & 3) == 3) {
+              uint4 q4 = make_uint4(ls[threadIdx.x], ls[PSG_WG + threadIdx.x], ls[2 * PSG_WG + threadIdx.x], ls[3 * PSG_WG + threadIdx.x]);
+              ((uint4 *)P.log)[((g + t) >> 2) * P.K + c.k] = q4;
+            }
+          } else if (CHECK_OVF) {
+            u32 old = atomicAdd(&P.gap[ni], 1u);
+            ovf |= (old == 0xFFFFFFFFu);
+          } else {
+            atomicAdd(&P.gap[ni], 1u);
+          }
+          if (--c.tcnt == 0) {
+            c.tcnt = 16;
+            c.tlo = (u64)c.nxt.x | ((u64)c.nxt.y << 32);
+            c.thi = (u64)c.nxt.z | ((u64)c.nxt.w << 32);
+            --c.cp;
+            if ((uintptr_t)c.cp > c.last_addr) c.nxt = *(c.cp - 1);
+          }
+        }
       }
     }
-    if (P.gt_out) P.gt_out[w - (P.ctx >> 5)] = gout;
-    gin = gin_next;
-    if (MODE == 2 && (steps & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
-      int full = steps & ~3;
-      uint4 q4 = make_uint4(lstage[threadIdx.x], (steps & 3) > 1 ? lstage[PSG_WG + threadIdx.x] : 0xFFFFFFFFu,
-                            (steps & 3) > 2 ? lstage[2 * PSG_WG + threadIdx.x] : 0xFFFFFFFFu, 0xFFFFFFFFu);
-      ((uint4 *)P.log)[((u - u0 + full) >> 2) * P.K + k] = q4;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      if (steps[q]) {
+        Chain &c = S[q];
+        if (P.gt_out) P.gt_out[c.w - (P.ctx >> 5)] = c.gout;
+        c.gin = c.gin_next;
+        ++c.w;
+        if (MODE == 2 && (steps[q] & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
+          int full = steps[q] & ~3;
+          const u32 *ls = lstage + q * 4 * PSG_WG;
+          uint4 q4 = make_uint4(ls[threadIdx.x], (steps[q] & 3) > 1 ? ls[PSG_WG + threadIdx.x] : 0xFFFFFFFFu,
+                                (steps[q] & 3) > 2 ? ls[2 * PSG_WG + threadIdx.x] : 0xFFFFFFFFu, 0xFFFFFFFFu);
+          ((uint4 *)P.log)[((g + full) >> 2) * P.K + c.k] = q4;
+        }
+      }
     }
   }
-  if (MODE == 2)   // a short (last) chain marks the rest of its log column as "no entry"
-    for (i64 st = ((u1 - u0) + 3) & ~(i64)3; st < P.L; st += 4)
-      ((uint4 *)P.log)[(st >> 2) * P.K + k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-  P.fin[k] = i;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    Chain &c = S[q];
+    if (c.k < 0) continue;
+    if (MODE == 2)   // a short (last) chain marks the rest of its log column as "no entry"
+      for (i64 st = ((c.u1 - c.u0) + 3) & ~(i64)3; st < P.L; st += 4)
+        ((uint4 *)P.log)[(st >> 2) * P.K + c.k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    P.fin[c.k] = c.i;
+  }
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
 }
 
@@ -696,22 +803,41 @@ template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams 
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
 }
-template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode) {
+// chains per lane: 2 for the layouts with at most two loads per query (symbol-major, sigma <= 16),
+// PSG_CPL=1|2 overrides
+static int chains_per_lane(const psg_rank *r) {
+  if (const char *e = getenv("PSG_CPL")) return atoi(e) == 2 ? 2 : 1;
+  (void)r;
+  return 1;   // measured (MI355X, 4 GiB bench): 2 chains/lane at 4 waves/SIMD == 1 chain/lane at 8 waves/SIMD
+}
+template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode, int cpl) {
   RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
-  dim3 grid((unsigned)cdiv(P.nchains, PSG_WG));
-  if (mode == 2) hipLaunchKernelGGL((stream_kernel<CNT, B, 2>), grid, dim3(PSG_WG), lds, stream(), R, P);
-  else if (mode == 1) hipLaunchKernelGGL((stream_kernel<CNT, B, 1>), grid, dim3(PSG_WG), lds, stream(), R, P);
-  else hipLaunchKernelGGL((stream_kernel<CNT, B, 0>), grid, dim3(PSG_WG), lds, stream(), R, P);
+  dim3 grid((unsigned)cdiv(cdiv(P.nchains, cpl), PSG_WG));
+#define PSG_LAUNCH(MODE_)                                                                                          \
+  do {                                                                                                             \
+    if (cpl == 2) hipLaunchKernelGGL((stream_kernel<CNT, B, MODE_, 2>), grid, dim3(PSG_WG), lds, stream(), R, P);  \
+    else hipLaunchKernelGGL((stream_kernel<CNT, B, MODE_, 1>), grid, dim3(PSG_WG), lds, stream(), R, P);           \
+  } while (0)
+  if (mode == 2) PSG_LAUNCH(2);
+  else if (mode == 1) PSG_LAUNCH(1);
+  else PSG_LAUNCH(0);
+#undef PSG_LAUNCH
 }
 
 // resident workgroups per CU of the stream kernel that will be launched (occupancy API)
-template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int *blocks) {
+template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int cpl, int *blocks) {
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   *blocks = 0;
-  if (mode == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 2>, PSG_WG, lds);
-  else if (mode == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 1>, PSG_WG, lds);
-  else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, 0>, PSG_WG, lds);
+#define PSG_OCC(MODE_)                                                                                                       \
+  do {                                                                                                                       \
+    if (cpl == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, lds);  \
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, lds);           \
+  } while (0)
+  if (mode == 2) PSG_OCC(2);
+  else if (mode == 1) PSG_OCC(1);
+  else PSG_OCC(0);
+#undef PSG_OCC
 }
 
 extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
@@ -773,15 +899,16 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
   }
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
   // pass time: every chain has the same length)
+  const int cpl = chains_per_lane(r);
   i64 Ktarget = max_chains;
   if (Ktarget <= 0) {
     int blocks = 0, dev = 0, cus = 256;
-    DISPATCH_LAYOUT(r, query_occupancy, r, mode, &blocks);
+    DISPATCH_LAYOUT(r, query_occupancy, r, mode, cpl, &blocks);
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (blocks < 1) blocks = 4;
     if (blocks > 8) blocks = 8;
-    Ktarget = (i64)blocks * cus * PSG_WG;
+    Ktarget = (i64)blocks * cus * PSG_WG * cpl;
   }
   i64 L = cdiv(cdiv(T, Ktarget), 64) * 64;
   i64 K = cdiv(T, L);
@@ -841,7 +968,7 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
       SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
     }
     ktm.start();
-    DISPATCH_LAYOUT(r, launch_stream, r, SP, mode);
+    DISPATCH_LAYOUT(r, launch_stream, r, SP, mode, cpl);
     ktm.stop();
     PSG_HIP(hipGetLastError());
     PSG_HIP(hipMemcpyAsync(fin.data(), fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
