@@ -33,12 +33,15 @@ sys.path.insert(0, ROOT)
 A_STREAM = 39.25      # algorithmic bytes per streamed suffix (b = 64)
 A_MERGE = 11.0        # algorithmic bytes per merged output suffix (merge.hpp:161)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-# HBM bytes per streamed suffix of stream_kernel<256,64> from the PMC passes committed in
-# profiles/r01_pmc_summary.csv: (FETCH_SIZE 2.865e8 KB + WRITE_SIZE 7.132e7 KB) * 1024 / 2^31.
+# HBM bytes per streamed suffix of the stream kernel, from the PMC passes committed in
+# profiles/r01_pmc_summary.csv: (FETCH_SIZE + WRITE_SIZE) * 1024 / 2^31, keyed by rank layout
+# (bytes of rank structure per BWT symbol):
+#   16.0 = symbol-major layout, rank-log mode: (1.468e8 + 1.049e7) KB -> 75.0 B/suffix
+#   17.0 = interleaved blocks B=64 with atomics (first version):          170.6 B/suffix
 # Calibration (profiles/r01_membench.txt + same csv): FETCH_SIZE*1024 is exact for random
 # 16-byte loads (64 B per request) and reads 1/2 for wide coalesced streams on gfx950; this
 # kernel's traffic is random-sector traffic, so no correction is applied.
-PMC_TRAFFIC_B_PER_SUFFIX = {17.0: 170.6}
+PMC_TRAFFIC_B_PER_SUFFIX = {16.0: 75.0, 17.0: 170.6}
 
 
 def parse():
@@ -307,7 +310,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (PMC_TRAFFIC_B_PER_SUFFIX.get(round(rk_bytes / ls, 1)) or 0) * stream_suffixes or None,
                          "traffic_source": "PMC FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_summary.csv (bytes per launch)",
-                         "random_access_ceiling": "profiles/r01_membench.txt: 2 dependent random sector loads + 1 random u32 atomic per step run at 11.0-11.2 G steps/s on this chip; stream_kernel reaches ~95% of that",
+                         "random_access_ceiling": "profiles/r01_membench.txt: dependent random 16-byte loads (one 64 B sector each) top out at 51 G/s on this chip = 3.3 TB/s of sectors; one sector per suffix is this kernel's floor",
                          "algorithmic_bytes_per_suffix": A_STREAM, "suffixes_per_launch": stream_suffixes,
                          "avg_launch_ms": 1e3 * kernel_s},
             "merge_roofline": {"achieved": A_MERGE * (oe - ob) / per["merge"] / 1e9, "unit": "GB/s", "note": "includes plan build (rank samples over the merge bitvector)"},
