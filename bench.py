@@ -218,10 +218,17 @@ def main():
             fin, st = api.stream_gap(rk, Lh["i0"], last_left, d_text.at(tb), te - tb, gt_in, start_rank, gap_ptr, gt_out,
                                      args.max_chains, right_context=ctx)
             t2 = t3 = time.perf_counter()
+            if os.environ.get("PSG_TIMING"):
+                ta = time.perf_counter(); api.sync(); tb_ = time.perf_counter(); api.sync(); tc = time.perf_counter()
+                print(f"[bench] after stream_gap: first sync {1e3*(tb_-ta):.2f} ms, second sync {1e3*(tc-tb_):.2f} ms", file=sys.stderr)
+                t2 = t3 = time.perf_counter()
             nb = api.gap_to_bitvector(gap_ptr, ls, mbv, n)
             assert nb == n, (nb, n)
             Lh["mbv"] = mbv
             t4 = time.perf_counter()
+            if timed:
+                times["to_bv_device"] = times.get("to_bv_device", 0.0) + api.last_kernel_ms() / 1e3
+                times["stream_hist_device"] = times.get("stream_hist_device", 0.0) + st.hist_ms / 1e3
         else:
             # gap array sharded by index range: rank-log all-to-all, slice histograms, bit all-reduce
             # (psascan_amd/distributed.py: a2a_pass; gloo-tested in tests/test_distributed_cpu.py)

@@ -7,6 +7,9 @@
 #include "dev_common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
 #include <vector>
 
 using namespace psg;
@@ -109,25 +112,38 @@ __global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap,
 
 extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *d_bv, int64_t cap_bits, int64_t *nbits) {
   PSG_REQUIRE(d_gap && d_bv && m >= 0 && nbits, "psg_gap_to_bitvector");
+  static const bool dbg = getenv("PSG_TIMING") != nullptr;
+  auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+  if (dbg) { double d0 = now(); (void)psg::sync_stream(); fprintf(stderr, "[psg_gap_to_bitvector]   drain at entry %.2f ms\n", now() - d0); }
+  double w0 = now();
   EventTimer tm; tm.start();
   i64 n = m + 1, ntiles = cdiv(n, TILE_V);
   DevBuf ts, tot;
   int rc;
   if ((rc = ts.alloc(ntiles * 8)) || (rc = tot.alloc(8))) return rc;
+  double w1 = now();
   hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, n, ts.as<u64>());
   PSG_HIP(hipGetLastError());
+  double x1 = now();
   if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  double x2 = now();
   u64 total = 0;
-  PSG_HIP(hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  double x3 = now();
+  PSG_HIP(psg::sync_stream());
+  if (dbg) fprintf(stderr, "[psg_gap_to_bitvector]   launch sum %.2f  launch scan %.2f  memcpyAsync %.2f  sync %.2f ms\n", x1 - w1, x2 - x1, x3 - x2, now() - x3);
+  memcpy(&total, pinned_buf(3, 64), 8);
+  double w2 = now();
   *nbits = m + (i64)total;
   if (*nbits > cap_bits) { set_error("psg_gap_to_bitvector: output capacity too small"); return PSG_EINVAL; }
   if ((rc = fill_ones(d_bv, *nbits))) return rc;
+  double w3 = now();
   hipLaunchKernelGGL(gap_to_bv_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, m, ts.as<u64>(), d_bv);
   PSG_HIP(hipGetLastError());
   tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
+  if (dbg) fprintf(stderr, "[psg_gap_to_bitvector] alloc %.2f  sum+scan+readback %.2f  fill_ones(host) %.2f  apply+sync %.2f ms\n", w1 - w0, w2 - w1, w3 - w2, now() - w3);
   return 0;
 }
 
@@ -180,7 +196,7 @@ extern "C" int psg_gap_slice_to_bits(const uint32_t *d_gap_slice, int64_t j0, in
   hipLaunchKernelGGL(gap_slice_bits_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, j0, count, m, (u64)ps_before,
                      ts.as<u64>(), d_bits);
   PSG_HIP(hipGetLastError());
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   return 0;
 }
 
@@ -257,16 +273,17 @@ extern "C" int psg_merge_bwt(const uint8_t *d_l, const uint8_t *d_r, int64_t ml,
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(tc.as<u64>(), ntiles, tot.as<u64>()))) return rc;
   u64 ones = 0;
-  PSG_HIP(hipMemcpyAsync(&ones, tot.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  PSG_HIP(psg::sync_stream());
+  memcpy(&ones, pinned_buf(3, 64), 8);
   if ((i64)ones != mr) { set_error("psg_merge_bwt: bitvector has " + std::to_string(ones) + " ones, expected " + std::to_string(mr)); return PSG_ECHECK; }
   PSG_HIP(hipMemsetAsync(bi0.p, 0xFF, 8, stream()));
   hipLaunchKernelGGL(merge_bwt_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_l, d_r, ml, mr, left_i0, right_i0,
                      (u32)left_last, d_bv, tc.as<u64>(), d_out, bi0.as<i64>());
   PSG_HIP(hipGetLastError());
   tm.stop();
-  PSG_HIP(hipMemcpyAsync(block_i0, bi0.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(block_i0, bi0.p, (size_t)(8))) return rc_;
+  PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
   if (*block_i0 < 0) { set_error("psg_merge_bwt: block_i0 not found"); return PSG_ECHECK; }
   return 0;
@@ -337,8 +354,8 @@ extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_
   if ((rc = scan_u64_inplace(tg.as<u64>(), ntiles, tot.as<u64>()))) return rc;
   if ((rc = scan_u64_inplace(to.as<u64>(), ntiles, tot.as<u64>() + 1))) return rc;
   u64 t[2];
-  PSG_HIP(hipMemcpyAsync(t, tot.p, 16, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(t, tot.p, (size_t)(16))) return rc_;
+  PSG_HIP(psg::sync_stream());
   if ((i64)t[0] != tail_len) { set_error("psg_split_gap: sum(block_gap)=" + std::to_string(t[0]) + " != tail_len=" + std::to_string(tail_len)); return PSG_ECHECK; }
   if ((i64)t[1] != mr) { set_error("psg_split_gap: bitvector ones=" + std::to_string(t[1]) + " != right size " + std::to_string(mr)); return PSG_ECHECK; }
   if ((rc = fill_ones(d_mbv_left, block + tail_len)) || (rc = fill_ones(d_mbv_right, mr + tail_len))) return rc;
@@ -346,7 +363,7 @@ extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_
                      d_mbv_left, d_mbv_right);
   PSG_HIP(hipGetLastError());
   tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
   return 0;
 }
@@ -381,13 +398,14 @@ extern "C" int psg_mbv_to_gap(const uint32_t *d_mbv, int64_t nbits, int64_t size
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(tc.as<u64>(), ntiles, tot.as<u64>()))) return rc;
   u64 zeros = 0;
-  PSG_HIP(hipMemcpyAsync(&zeros, tot.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  PSG_HIP(psg::sync_stream());
+  memcpy(&zeros, pinned_buf(3, 64), 8);
   if ((i64)zeros != size) { set_error("psg_mbv_to_gap: " + std::to_string(zeros) + " zero bits, expected " + std::to_string(size)); return PSG_ECHECK; }
   hipLaunchKernelGGL(zpos_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_mbv, nbits, tc.as<u64>(), zp.as<u64>());
   hipLaunchKernelGGL(zpos_to_gap_kernel, dim3((unsigned)cdiv(size + 1, PSG_WG)), dim3(PSG_WG), 0, stream(), zp.as<u64>(), size, nbits, d_gap_out);
   PSG_HIP(hipGetLastError());
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   return 0;
 }
 
@@ -429,13 +447,14 @@ extern "C" int psg_vbyte_encode(const uint64_t *d_vals, int64_t count, uint8_t *
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, tot.as<u64>()))) return rc;
   u64 total = 0;
-  PSG_HIP(hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  PSG_HIP(psg::sync_stream());
+  memcpy(&total, pinned_buf(3, 64), 8);
   *nbytes = (i64)total;
   if ((i64)total > cap) { set_error("psg_vbyte_encode: output capacity too small"); return PSG_EINVAL; }
   hipLaunchKernelGGL(vbyte_write_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_vals, count, ts.as<u64>(), d_out, cap);
   PSG_HIP(hipGetLastError());
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   return 0;
 }
 
@@ -573,9 +592,7 @@ extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_pl
       hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), L.mbv, L.nbits, (u64 *)samp);
       if ((rc = scan_u64_inplace((u64 *)samp, ntiles, tot.as<u64>()))) { psg_merge_plan_free(p); return rc; }
       u64 ones = 0;
-      hipError_t e2 = hipMemcpyAsync(&ones, tot.p, 8, hipMemcpyDeviceToHost, stream());
-      hipError_t e3 = hipStreamSynchronize(stream());
-      if (e2 != hipSuccess || e3 != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: device error"); return PSG_EDEVICE; }
+      if ((rc = psg::copy_d2h(&ones, tot.p, 8))) { psg_merge_plan_free(p); return rc; }
       if ((i64)ones != nh[h + 1]) {
         psg_merge_plan_free(p);
         set_error("merge plan: level " + std::to_string(h) + " has " + std::to_string(ones) + " ones, expected " + std::to_string(nh[h + 1]));
@@ -587,9 +604,7 @@ extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_pl
   }
   hipError_t e = psg::pool_alloc((void **)&p->d_levels, sizeof(MergeLevel) * (size_t)H);
   if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
-  e = hipMemcpyAsync(p->d_levels, p->levels.data(), sizeof(MergeLevel) * (size_t)H, hipMemcpyHostToDevice, stream());
-  hipError_t e3 = hipStreamSynchronize(stream());
-  if (e != hipSuccess || e3 != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: upload failed"); return PSG_EDEVICE; }
+  if ((rc = psg::copy_h2d(p->d_levels, p->levels.data(), sizeof(MergeLevel) * (size_t)H))) { psg_merge_plan_free(p); return rc; }
   *out = p;
   return 0;
 }
@@ -602,7 +617,7 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)cdiv(out_count, TILE_B)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
   PSG_HIP(hipGetLastError());
   tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
   return 0;
 }

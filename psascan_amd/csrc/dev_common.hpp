@@ -42,6 +42,15 @@ void pool_free(void *p);
 void pool_trim();
 size_t pool_cached_bytes();   // bytes held in the cache (reusable without asking the driver)
 
+// grow-only pinned host buffers (slot 0..7), for small read-backs and the per-chain arrays
+void *pinned_buf(int slot, size_t bytes);
+// Synchronous host<->device copies staged through pinned memory.  Pageable host pointers are never
+// handed to HIP: ROCr registers them as userptr ranges, and when the host later unmaps / trims
+// that memory the KFD MMU notifier evicts and restores the process' queues -- measured as 20-30 ms
+// stalls of the next HIP call in a run-dependent fraction of the processes.
+int copy_h2d(void *d, const void *h, size_t bytes);
+int copy_d2h(void *h, const void *d, size_t bytes);
+
 // RAII device buffer for temporaries
 struct DevBuf {
   void *p = nullptr;
@@ -60,10 +69,19 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
+// Wait for the library stream by POLLING an event: hipStreamSynchronize's interrupt-driven wait was
+// measured to return 15-25 ms late for ~6 ms of GPU work in some processes (MI355X, ROCm 7.2).
+hipError_t sync_stream();
+
+// events are recycled: hipEventCreate/Destroy per call showed up as multi-ms host stalls
+hipEvent_t event_acquire();
+void event_release(hipEvent_t e);
 struct EventTimer {
   hipEvent_t a = nullptr, b = nullptr;
-  EventTimer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
-  ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  EventTimer() { a = event_acquire(); b = event_acquire(); }
+  ~EventTimer() { event_release(a); event_release(b); }
+  EventTimer(const EventTimer &) = delete;
+  EventTimer &operator=(const EventTimer &) = delete;
   void start() { (void)hipEventRecord(a, stream()); }
   void stop() { (void)hipEventRecord(b, stream()); }
   double ms() { float f = 0; (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&f, a, b); return f; }

@@ -13,6 +13,7 @@
 #include "dev_common.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 using namespace psg;
 
@@ -252,14 +253,15 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(cnt.as<u64>(), nwin, tot.as<u64>()))) return rc;
   u64 items = 0;
-  PSG_HIP(hipMemcpyAsync(&items, tot.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  PSG_HIP(psg::sync_stream());
+  memcpy(&items, pinned_buf(3, 64), 8);
   if (items > 0) {
     hipLaunchKernelGGL(hist_items_kernel, dim3((unsigned)items), dim3(PSG_WG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap);
     PSG_HIP(hipGetLastError());
   }
   tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   if (ms) *ms = tm.ms();
   return 0;
 }
@@ -304,8 +306,8 @@ extern "C" int psg_log_partition(const uint32_t *d_log, int64_t nlog, int64_t m,
   hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, off.as<u64>(), d_out);
   PSG_HIP(hipGetLastError());
   u64 bb[PBINS + 1];
-  PSG_HIP(hipMemcpyAsync(bb, bin_base.p, sizeof bb, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(bb, bin_base.p, (size_t)(sizeof bb))) return rc_;
+  PSG_HIP(psg::sync_stream());
   for (int p = 0; p <= nparts; ++p) h_offsets[p] = (i64)bb[p == nparts ? PBINS : nb * p / nparts];
   return 0;
 }

@@ -43,7 +43,7 @@ extern "C" int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, ui
   if (n == 0) return 0;
   hipLaunchKernelGGL(gen_text_kernel, dim3((unsigned)cdiv(cdiv(n, 8), PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, mode, sigma, seed);
   PSG_HIP(hipGetLastError());
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   return 0;
 }
 
@@ -121,8 +121,8 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
   if ((rc = hist.alloc(256 * 8))) return rc;
   // reuse the rank histogram through a tiny local kernel: count on a sample is not enough, do it exactly
   std::vector<u8> sample((size_t)std::min<i64>(n, 1 << 22));
-  PSG_HIP(hipMemcpyAsync(sample.data(), d_text, sample.size(), hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(sample.data(), d_text, (size_t)(sample.size()))) return rc_;
+  PSG_HIP(psg::sync_stream());
   bool present[256] = {false};
   for (u8 c : sample) present[c] = true;
   KeyCfg cfg;
@@ -152,8 +152,8 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
   hipLaunchKernelGGL(bwt_gt_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, d_psa, (const i64 *)((u8 *)misc.p + 16), d_bwt, d_gt_begin);
   PSG_HIP(hipGetLastError());
   u64 h[4];
-  PSG_HIP(hipMemcpyAsync(h, misc.p, 32, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(h, misc.p, (size_t)(32))) return rc_;
+  PSG_HIP(psg::sync_stream());
   if ((int)(h[1] & 0xFFFFFFFF)) { set_error("psgx_sort_halfblock: an equal-prefix group is too large (text too repetitive for the prefix-key sorter)"); return PSG_ECHECK; }
   if (tie_groups) *tie_groups = (i64)h[0];
   *i0 = (i64)h[2];
@@ -193,8 +193,8 @@ extern "C" int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d
     PSG_HIP(hipGetLastError());
   }
   u64 h[2];
-  PSG_HIP(hipMemcpyAsync(h, acc.p, 16, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(h, acc.p, (size_t)(16))) return rc_;
+  PSG_HIP(psg::sync_stream());
   *sum = h[0]; *bad_pairs = (i64)h[1];
   return 0;
 }

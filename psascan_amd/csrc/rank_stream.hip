@@ -631,10 +631,8 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   auto fail = [&](int code) { psg::pool_free(entries); psg::pool_free(pool); return code; };
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(nseg * 256 * 4)) || (rc = group_sum.alloc(ngroups * 256 * 8)) || (rc = t2_d.alloc(256 * 8)) || (rc = misc.alloc(8)))
     return fail(rc);
-  hipError_t e1 = hipMemcpyAsync(code_d.p, ident, 256, hipMemcpyHostToDevice, stream());
-  hipError_t e2 = hipMemcpyAsync(t2_d.p, t2, sizeof t2, hipMemcpyHostToDevice, stream());
-  hipError_t e3 = hipMemsetAsync(misc.p, 0, 8, stream());
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("sm_build: copy failed"); return fail(PSG_EDEVICE); }
+  if ((rc = psg::copy_h2d(code_d.p, ident, 256)) || (rc = psg::copy_h2d(t2_d.p, t2, sizeof t2))) return fail(rc);
+  if (hipMemsetAsync(misc.p, 0, 8, stream()) != hipSuccess) { set_error("sm_build: memset failed"); return fail(PSG_EDEVICE); }
   hipLaunchKernelGGL((seg_hist_kernel<256, 64>), dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>());
   hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * 256, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt.as<u32>(), nseg, 256, group_sum.as<u64>(), ngroups);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
@@ -642,9 +640,8 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
                      (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
   u32 st[2] = {0, 0};
   hipError_t e4 = hipGetLastError();
-  hipError_t e5 = hipMemcpyAsync(st, misc.p, 8, hipMemcpyDeviceToHost, stream());
-  hipError_t e6 = hipStreamSynchronize(stream());
-  if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4 != hipSuccess ? e4 : e6)); return fail(PSG_EDEVICE); }
+  if (e4 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4)); return fail(PSG_EDEVICE); }
+  if ((rc = psg::copy_d2h(st, misc.p, 8))) return fail(rc);
   if (st[1] || st[0] > pool_cap) { psg::pool_free(entries); psg::pool_free(pool); return 0; }   // too many dense buckets: block layout instead
   r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = 1;
   r->d_blocks = entries; r->d_aux = pool; r->blocks_bytes = entries_bytes + (i64)pool_cap * 32;
@@ -669,8 +666,8 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
     PSG_HIP(hipGetLastError());
   }
   u64 h[256];
-  PSG_HIP(hipMemcpyAsync(h, hist.p, sizeof h, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(h, hist.p, (size_t)(sizeof h))) return rc_;
+  PSG_HIP(psg::sync_stream());
   psg_rank *r = new psg_rank();
   r->m = m;
   int sigma = 0;
@@ -688,7 +685,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
       if (rc) { delete r; return rc; }
       if (!fell_back) {
         tm.stop();
-        PSG_HIP(hipStreamSynchronize(stream()));
+        PSG_HIP(psg::sync_stream());
         note_kernel_ms(tm.ms());
         *out = r;
         return 0;
@@ -727,7 +724,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   hipError_t e = psg::pool_alloc((void **)&r->d_blocks, (size_t)r->blocks_bytes + 64);   // +64: the upper-part read of the last block may run 16 B over
   if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
-  PSG_HIP(hipMemcpyAsync(code_d.p, r->code, 256, hipMemcpyHostToDevice, stream()));
+  if (int rc_ = psg::copy_h2d(code_d.p, r->code, (size_t)(256))) return rc_;
   if (r->cnt == 4) launch_build<4, 48>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
   else if (r->cnt == 16) launch_build<16, 64>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
   else if (r->B == 32) launch_build<256, 32>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
@@ -739,10 +736,10 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   r->h_sb.assign((size_t)r->nsb * r->cnt, 0);
   for (int s = 0; s < r->nsb; ++s) {
     i64 g = (((i64)s << SB_SHIFT) / SEG_BLOCKS) / GROUP_SEGS;
-    PSG_HIP(hipMemcpyAsync(&r->h_sb[(size_t)s * r->cnt], group_sum.as<u64>() + g * r->cnt, (size_t)r->cnt * 8, hipMemcpyDeviceToHost, stream()));
+    if (int rc_ = psg::copy_d2h(&r->h_sb[(size_t)s * r->cnt], group_sum.as<u64>() + g * r->cnt, (size_t)((size_t)r->cnt * 8))) return rc_;
   }
   tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
   *out = r;
   return 0;
@@ -773,9 +770,9 @@ static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &t
   for (int c = 0; c < 256; ++c) { t[c] = (u64)r->count[c]; t[256 + c] = r->t2[c]; }
   if (int rc = T1.alloc((i64)h.size() * 8)) return rc;
   if (int rc = tot.alloc(512 * 8)) return rc;
-  PSG_HIP(hipMemcpyAsync(T1.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream()));
-  PSG_HIP(hipMemcpyAsync(tot.p, t.data(), 512 * 8, hipMemcpyHostToDevice, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));  // h, t go out of scope
+  if (int rc_ = psg::copy_h2d(T1.p, h.data(), (size_t)(h.size() * 8))) return rc_;
+  if (int rc_ = psg::copy_h2d(tot.p, t.data(), (size_t)(512 * 8))) return rc_;
+  PSG_HIP(psg::sync_stream());  // h, t go out of scope
   return 0;
 }
 
@@ -794,7 +791,7 @@ extern "C" int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uin
   if (int rc = make_tables(r, nullptr, T1, tot)) return rc;
   DISPATCH_LAYOUT(r, launch_query, r, T1.as<u64>(), tot.as<u64>(), d_i, d_c, nq, d_out);
   PSG_HIP(hipGetLastError());
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
   return 0;
 }
 
@@ -917,7 +914,11 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
   int rc;
   if ((rc = lo_d.alloc(K * 8)) || (rc = hi_d.alloc(K * 8)) || (rc = fin_d.alloc(K * 8)) || (rc = list_d.alloc(K * 8)) || (rc = flag_d.alloc(4))) return rc;
   PSG_HIP(hipMemsetAsync(flag_d.p, 0, 4, stream()));
-  std::vector<i64> lo(K), hi(K), fin(K, -1), list;
+  // pinned host mirrors: read-backs into pageable memory go through a slow staging path
+  i64 *lo = (i64 *)pinned_buf(0, (size_t)K * 8), *hi = (i64 *)pinned_buf(1, (size_t)K * 8), *fin = (i64 *)pinned_buf(2, (size_t)K * 8);
+  if (!lo || !hi || !fin) { set_error("stream: pinned host allocation failed"); return PSG_ENOMEM; }
+  for (i64 k = 0; k < K; ++k) fin[k] = -1;
+  std::vector<i64> list;
   std::vector<char> resolved(K, 0), done(K, 0);
   WarmParams WP{d_tail, T + ctx, ctx, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
   // warm-up with growing W for the chains that did not resolve
@@ -925,9 +926,9 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
   for (int attempt = 0; attempt < 4; ++attempt) {
     DISPATCH_LAYOUT(r, launch_warm, r, WP);
     PSG_HIP(hipGetLastError());
-    PSG_HIP(hipMemcpyAsync(lo.data(), lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(hipMemcpyAsync(hi.data(), hi_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(hipStreamSynchronize(stream()));
+    PSG_HIP(hipMemcpyAsync(lo, lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(hipMemcpyAsync(hi, hi_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(psg::sync_stream());
     list.clear();
     for (i64 k = 0; k < K; ++k) { resolved[k] = lo[k] == hi[k]; if (!resolved[k]) list.push_back(k); }
     st.warmup_steps = WP.W;
@@ -936,8 +937,8 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
     WP.W *= 16;
     WP.nitems = nun;
     WP.list = list_d.as<i64>();
-    PSG_HIP(hipMemcpyAsync(list_d.p, list.data(), nun * 8, hipMemcpyHostToDevice, stream()));
-    PSG_HIP(hipStreamSynchronize(stream()));
+    if (int rc_ = psg::copy_h2d(list_d.p, list.data(), (size_t)(nun * 8))) return rc_;
+    PSG_HIP(psg::sync_stream());
   }
   st.unresolved = nun;
   if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
@@ -960,19 +961,19 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
       }
     if (ready.empty()) { set_error("stream: no runnable chain (internal error)"); return PSG_ECHECK; }
     if (nun > 0) {  // start ranks may have been patched on the host
-      PSG_HIP(hipMemcpyAsync(lo_d.p, lo.data(), K * 8, hipMemcpyHostToDevice, stream()));
+      PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));
     }
     if ((i64)ready.size() == K) { SP.list = nullptr; SP.nchains = K; }
     else {
-      PSG_HIP(hipMemcpyAsync(list_d.p, ready.data(), ready.size() * 8, hipMemcpyHostToDevice, stream()));
+      if (int rc_ = psg::copy_h2d(list_d.p, ready.data(), (size_t)(ready.size() * 8))) return rc_;
       SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
     }
     ktm.start();
     DISPATCH_LAYOUT(r, launch_stream, r, SP, mode, cpl);
     ktm.stop();
     PSG_HIP(hipGetLastError());
-    PSG_HIP(hipMemcpyAsync(fin.data(), fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(hipStreamSynchronize(stream()));
+    PSG_HIP(hipMemcpyAsync(fin, fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(psg::sync_stream());
     kms += ktm.ms();
     for (i64 k : ready) done[k] = 1;
     ndone += (i64)ready.size();
@@ -996,9 +997,10 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
   }
   st.hist_ms = hist_ms;
   int ovf = 0;
-  PSG_HIP(hipMemcpyAsync(&ovf, flag_d.p, 4, hipMemcpyDeviceToHost, stream()));
+  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), flag_d.p, 4, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
   total_tm.stop();
-  PSG_HIP(hipStreamSynchronize(stream()));
+  PSG_HIP(psg::sync_stream());
+  memcpy(&ovf, pinned_buf(3, 64), 4);
   if (ovf) { set_error("stream: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
   st.kernel_ms = kms;
   st.total_ms = total_tm.ms();

@@ -1,6 +1,8 @@
 // runtime.hip -- device selection, memory helpers, error state, small bit utilities.
 #include "dev_common.hpp"
 
+#include <algorithm>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -74,6 +76,79 @@ void pool_trim() {
   }
   if (!blocks.empty() && g_stream) (void)hipStreamSynchronize(g_stream);
   for (void *b : blocks) (void)hipFree(b);
+}
+
+// ---- event recycling -----------------------------------------------------------------------
+static std::vector<hipEvent_t> g_events;
+hipEvent_t event_acquire() {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_events.empty()) { hipEvent_t e = g_events.back(); g_events.pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void event_release(hipEvent_t e) {
+  if (!e) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_events.push_back(e);
+}
+
+// ---- polling stream sync -----------------------------------------------------------------
+hipError_t sync_stream() {
+  hipEvent_t e = event_acquire();
+  if (!e) return hipStreamSynchronize(g_stream);
+  hipError_t rc = hipEventRecord(e, g_stream);
+  if (rc == hipSuccess) {
+    while ((rc = hipEventQuery(e)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  event_release(e);
+  if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamSynchronize(g_stream); }
+  return rc;
+}
+
+// ---- pinned host scratch -----------------------------------------------------------------
+static void *g_pin[8] = {nullptr};
+static size_t g_pin_bytes[8] = {0};
+void *pinned_buf(int slot, size_t bytes) {
+  if (slot < 0 || slot >= 8) return nullptr;
+  if (bytes < 4096) bytes = 4096;
+  if (g_pin_bytes[slot] >= bytes) return g_pin[slot];
+  if (g_pin[slot]) { if (g_stream) (void)hipStreamSynchronize(g_stream);  /* rare: keep the blocking wait */ (void)hipHostFree(g_pin[slot]); g_pin[slot] = nullptr; g_pin_bytes[slot] = 0; }
+  size_t cap = bytes + bytes / 2;
+  if (hipHostMalloc(&g_pin[slot], cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_pin[slot] = nullptr; return nullptr; }
+  g_pin_bytes[slot] = cap;
+  return g_pin[slot];
+}
+
+// ---- staged host <-> device copies ----------------------------------------------------------
+static const size_t STAGE_BYTES = (size_t)32 << 20;
+int copy_h2d(void *d, const void *h, size_t bytes) {
+  for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+    size_t n = std::min(STAGE_BYTES, bytes - off);
+    void *pin = pinned_buf(7, n);
+    if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
+    memcpy(pin, (const char *)h + off, n);
+    PSG_HIP(hipMemcpyAsync((char *)d + off, pin, n, hipMemcpyHostToDevice, g_stream));
+    PSG_HIP(sync_stream());
+  }
+  return 0;
+}
+int copy_d2h(void *h, const void *d, size_t bytes) {
+  for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+    size_t n = std::min(STAGE_BYTES, bytes - off);
+    void *pin = pinned_buf(7, n);
+    if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
+    PSG_HIP(hipMemcpyAsync(pin, (const char *)d + off, n, hipMemcpyDeviceToHost, g_stream));
+    PSG_HIP(sync_stream());
+    memcpy((char *)h + off, pin, n);
+  }
+  return 0;
 }
 
 // ---- single-workgroup scan ------------------------------------------------------------
@@ -196,18 +271,18 @@ int psg_memset(void *d_ptr, int value, int64_t bytes) {
   return 0;
 }
 int psg_h2d(void *d, const void *h, int64_t bytes) {
-  if (bytes > 0) { PSG_HIP(hipMemcpyAsync(d, h, (size_t)bytes, hipMemcpyHostToDevice, stream())); PSG_HIP(hipStreamSynchronize(stream())); }
+  if (bytes > 0) return psg::copy_h2d(d, h, (size_t)bytes);
   return 0;
 }
 int psg_d2h(void *h, const void *d, int64_t bytes) {
-  if (bytes > 0) { PSG_HIP(hipMemcpyAsync(h, d, (size_t)bytes, hipMemcpyDeviceToHost, stream())); PSG_HIP(hipStreamSynchronize(stream())); }
+  if (bytes > 0) return psg::copy_d2h(h, d, (size_t)bytes);
   return 0;
 }
 int psg_d2d(void *dd, const void *ds, int64_t bytes) {
   if (bytes > 0) PSG_HIP(hipMemcpyAsync(dd, ds, (size_t)bytes, hipMemcpyDeviceToDevice, stream()));
   return 0;
 }
-int psg_sync(void) { PSG_HIP(hipStreamSynchronize(stream())); return 0; }
+int psg_sync(void) { PSG_HIP(psg::sync_stream()); return 0; }
 
 int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t src_bit, int64_t nbits) {
   PSG_REQUIRE(dst_bit >= 0 && src_bit >= 0 && nbits >= 0, "psg_bitcopy");
@@ -232,8 +307,8 @@ int psg_popcount(const uint32_t *d_bits, int64_t nbits, int64_t *ones) {
     PSG_HIP(hipGetLastError());
   }
   u64 v = 0;
-  PSG_HIP(hipMemcpyAsync(&v, acc.p, 8, hipMemcpyDeviceToHost, stream()));
-  PSG_HIP(hipStreamSynchronize(stream()));
+  if (int rc_ = psg::copy_d2h(&v, acc.p, 8)) return rc_;
+  PSG_HIP(psg::sync_stream());
   *ones = (i64)v;
   return 0;
 }
