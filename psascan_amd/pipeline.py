@@ -118,6 +118,18 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
             idx = n - j
             return (int(cur_host[idx >> 3]) >> (idx & 7)) & 1
 
+        def gt_tail_e_bits(count, cur_host=cur_host, e=e):
+            """packed bits (LSB-first), bit v = gt_tail_e(v) for v in [0, count]"""
+            out = np.zeros(count + 1, np.uint8)
+            if cur_host is not None:
+                vmax = min(count, n - e - 1)                 # positions e+v < n
+                if vmax >= 1:
+                    allbits = np.unpackbits(cur_host, bitorder="little")
+                    idx = n - (e + np.arange(1, vmax + 1))
+                    out[1: vmax + 1] = allbits[idx]
+            return np.packbits(out, bitorder="little")
+        gt_tail_e.bits = gt_tail_e_bits
+
         R = None
         if rs > 0:
             R = sorter(text, mid, e, gt_tail_e)
@@ -130,6 +142,15 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
                 j = mid + v            # j in (mid, e]: right half's gt_begin, u = e - j
                 u = e - j
                 return (int(rgt_host[u >> 3]) >> (u & 7)) & 1
+
+            def gt_tail_mid_bits(count, rgt_host=rgt_host, e=e, mid=mid):
+                out = np.zeros(count + 1, np.uint8)
+                vmax = min(count, e - mid)
+                if rgt_host is not None and vmax >= 1:
+                    allbits = np.unpackbits(rgt_host, bitorder="little")
+                    out[1: vmax + 1] = allbits[e - (mid + np.arange(1, vmax + 1))]
+                return np.packbits(out, bitorder="little")
+            gt_tail_mid.bits = gt_tail_mid_bits
         else:
             gt_tail_mid = gt_tail_e
         L = sorter(text, b, mid, gt_tail_mid)

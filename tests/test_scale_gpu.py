@@ -27,3 +27,34 @@ def test_multiblock_properties(gpu_lib, mode, sigma, mib, block_mib):
     sa_head = np.frombuffer(api.download(d_out, np.uint8, 50).tobytes(), np.uint8).reshape(-1, 5)
     first = int(sum(int(sa_head[0, b]) << (8 * b) for b in range(5)))
     assert text[first] == text.min()
+
+
+def english_like(n, seed=1, nwords=4096):
+    """Zipfian words over a skewed 26-letter alphabet: repeats of tens of bytes, sigma = 28."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", np.uint8)
+    lp = 1.0 / np.arange(1, 27) ** 0.9
+    lp /= lp.sum()
+    words = [bytes(rng.choice(letters, l, p=lp)) for l in rng.integers(2, 10, nwords)]
+    wp = 1.0 / np.arange(1, nwords + 1)
+    wp /= wp.sum()
+    out = bytearray()
+    while len(out) < n:
+        out += b" ".join(words[i] for i in rng.choice(nwords, 200000, p=wp)) + b". "
+    return np.frombuffer(bytes(out[:n]), np.uint8).copy()
+
+
+def test_english_like_with_host_sorter(gpu_lib):
+    """configs[2]-shaped input at test scale: skewed alphabet (frequent symbols in BITMAP mode, rare in
+    LIST mode, dense buckets in the overflow pool), longer repeats, multi-block, host SA-IS sorter."""
+    from psascan_amd import api, extras, pipeline
+    from psascan_amd.hostsort import HostSorter
+    n = 40 << 20
+    text = english_like(n, seed=3)
+    d_text = api.upload(text, pad_to=16)
+    stats = []
+    d_out = pipeline.construct_sa5(text, 10 << 20, 1 << 40, HostSorter(), stats=stats, d_text=d_text, return_device=True)
+    bad, s = extras.check_sa5(d_text, n, d_out, n, samples=1 << 20, seed=9)
+    assert bad == 0 and s == (n * (n - 1) // 2) % (1 << 64)
+    assert sum(p[3].unresolved for p in stats) >= 0
+    print("english-like passes:", [(p[0], p[3].n_chains, p[3].warmup_steps, p[3].unresolved, p[3].rounds) for p in stats])
