@@ -154,7 +154,10 @@ def main():
             local = 0
         torch.cuda.set_device(local)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except TypeError:      # older torch: no device_id argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
     import numpy as np

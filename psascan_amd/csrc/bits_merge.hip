@@ -525,34 +525,42 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
     u32 tot1;
     u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
     int z = e0 - (int)o;
+    // survivors (bit 1) are compacted to the front of the other buffer, own elements (bit 0) to its
+    // back, so that BOTH are then handled by coalesced loops (own element i <-> PSA index zeros_q0 + i)
     for (int q = 0; q < n; ++q) {
       int slot = identity ? e0 + q : cur[s][e0 + q];
       int below = __popc(bits & ((1u << q) - 1u));
       if ((bits >> q) & 1u) cur[s ^ 1][o + below] = (u16)slot;
-      else {
-        i64 idx = zeros_q0 + z + q - below;
-        u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
-        vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
-      }
+      else cur[s ^ 1][TILE_B - 1 - (z + q - below)] = (u16)slot;
+    }
+    __syncthreads();
+    int nown = cnt - (int)tot1;
+    for (int i = threadIdx.x; i < nown; i += PSG_WG) {
+      int slot = cur[s ^ 1][TILE_B - 1 - i];
+      i64 idx = zeros_q0 + i;
+      u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
+      vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
     }
     __syncthreads();
     q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
   }
   __syncthreads();
-  // pack 40-bit little-endian (types/uint40.hpp:42-104)
-  u8 *o8 = out + 5 * (x0 - out_begin);
-  int nbytes = 5 * len, nd = nbytes >> 2;
-  for (int d = threadIdx.x; d < nd; d += PSG_WG) {
-    u32 w = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int bb = 4 * d + r, e = bb / 5, rr = bb - 5 * e;
-      u32 byte = rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e];
-      w |= byte << (8 * r);
-    }
-    *(u32 *)(o8 + 4 * d) = w;
+  // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords per thread
+  u32 *o32 = (u32 *)(out + 5 * (x0 - out_begin));
+  int nq = len >> 2;
+  for (int g4 = threadIdx.x; g4 < nq; g4 += PSG_WG) {
+    int e = 4 * g4;
+    u32 l0 = vlo[e], l1 = vlo[e + 1], l2 = vlo[e + 2], l3 = vlo[e + 3];
+    u32 h0 = vhi[e], h1 = vhi[e + 1], h2 = vhi[e + 2], h3 = vhi[e + 3];
+    u32 *dst = o32 + 5 * g4;
+    dst[0] = l0;
+    dst[1] = h0 | (l1 << 8);
+    dst[2] = (l1 >> 24) | (h1 << 8) | (l2 << 16);
+    dst[3] = (l2 >> 16) | (h2 << 16) | (l3 << 24);
+    dst[4] = (l3 >> 8) | (h3 << 24);
   }
-  for (int bb = nd * 4 + threadIdx.x; bb < nbytes; bb += PSG_WG) {
+  u8 *o8 = out + 5 * (x0 - out_begin);
+  for (int bb = nq * 20 + threadIdx.x; bb < 5 * len; bb += PSG_WG) {   // ragged tail of the last tile
     int e = bb / 5, rr = bb - 5 * e;
     o8[bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
   }

@@ -891,6 +891,7 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
     const char *e = getenv("PSG_GAP_MODE");   // "atomic" | "log" | unset = auto
     bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
     if (e && !strcmp(e, "atomic")) want_log = false;
+    if (e && !strcmp(e, "ovf")) { want_log = false; mode = 1; }   // tests: force the overflow-checking atomic kernel
     if (want_log && r->m < 0xFFFFFFFFll && mode == 0) mode = 2;
     if (log_out) mode = 2;   // the caller wants the log itself
   }

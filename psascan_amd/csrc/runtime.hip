@@ -152,21 +152,27 @@ int copy_d2h(void *h, const void *d, size_t bytes) {
 }
 
 // ---- single-workgroup scan ------------------------------------------------------------
+// 1024 threads x 4 consecutive values per iteration (the tile-sum arrays have ~1 M entries)
 __global__ __launch_bounds__(1024) void scan_u64_kernel(u64 *vals, i64 n, u64 *total) {
   __shared__ u64 wsum[16];
   __shared__ u64 carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   int w = threadIdx.x >> 6;
-  for (i64 base = 0; base < n; base += 1024) {
-    i64 k = base + threadIdx.x;
-    u64 v = k < n ? vals[k] : 0;
-    u64 inc = wave_incl_scan(v);
+  for (i64 base = 0; base < n; base += 4096) {
+    i64 k = base + (i64)threadIdx.x * 4;
+    u64 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = k + q < n ? vals[k + q] : 0;
+    u64 s = v[0] + v[1] + v[2] + v[3];
+    u64 inc = wave_incl_scan(s);
     if (lane_id() == 63) wsum[w] = inc;
     __syncthreads();
     u64 pre = carry_s, tot = 0;
-    for (int q = 0; q < 16; ++q) { u64 s = wsum[q]; if (q < w) pre += s; tot += s; }
-    if (k < n) vals[k] = pre + inc - v;
+    for (int q = 0; q < 16; ++q) { u64 x = wsum[q]; if (q < w) pre += x; tot += x; }
+    u64 run = pre + inc - s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (k + q < n) vals[k + q] = run; run += v[q]; }
     __syncthreads();
     if (threadIdx.x == 0) carry_s += tot;
     __syncthreads();

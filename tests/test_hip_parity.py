@@ -148,6 +148,31 @@ def test_stream_gap_log_mode(A, kind, monkeypatch):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+def test_stream_gap_overflow_checking_mode(A, monkeypatch):
+    """the kernel variant used for tails of >= 2^32 suffixes (returning atomics + overflow flag)"""
+    monkeypatch.setenv("PSG_GAP_MODE", "ovf")
+    n = 30000
+    t = make_text("sig12", n, 8)
+    b, e = 500, 9000
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m, T = e - b, n - e
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    d_gap = A.zeros(4 * (m + 2))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 100)
+    assert fin == want_fin and st.hist_ms == 0
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap)
+    # a counter at 2^32-1 must be reported, not wrapped silently
+    from psascan_amd._lib import PsgError
+    hot = int(np.argmax(want_gap))
+    g = np.zeros(m + 1, np.uint32); g[hot] = 0xFFFFFFFF
+    with pytest.raises(PsgError) as ei:
+        A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, A.upload(g), d_gtout, 100)
+    assert ei.value.code == -4
+
+
 @pytest.mark.parametrize("m,nlog,skew", [(100, 5000, 0), (66666, 133504, 0), (70000, 300, 0), (1 << 20, 1 << 22, 0),
                                          (9_000_000, 3_000_000, 0), (20_000_000, 6_000_000, 1), (5000, 2_000_000, 2)])
 def test_gap_hist_from_log(A, gpu_lib, m, nlog, skew):
