@@ -168,7 +168,7 @@ __global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 
 }
 
 // one work item = up to CAP log entries of one window: LDS histogram, coalesced add to the gap array
-__global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap) {
+__global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap, int *ovf) {
   __shared__ __attribute__((aligned(16))) u32 h[WSIZE];
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
       if (c.x | c.y | c.z | c.w) {
         uint4 *gp = (uint4 *)(gap + base) + k;
         uint4 g = *gp;
+        uint4 o = g;
         g.x += c.x; g.y += c.y; g.z += c.z; g.w += c.w;
+        if (g.x < o.x || g.y < o.y || g.z < o.z || g.w < o.w) *ovf = 1;   // a u32 gap counter wrapped
         *gp = g;
       }
     }
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
       u32 c = h[k];
       i64 idx = base + k;
       if (c && idx <= m) {
-        if (single) gap[idx] += c; else atomicAdd(&gap[idx], c);
+        if (single) { u32 o = gap[idx]; gap[idx] = o + c; if (o + c < o) *ovf = 1; }
+        else if (atomicAdd(&gap[idx], c) + c < c) *ovf = 1;
       }
     }
   }
@@ -229,8 +232,10 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, PT)));
-  DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot;
+  DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot, ovf;
   int rc;
+  if ((rc = ovf.alloc(4))) return rc;
+  PSG_HIP(hipMemsetAsync(ovf.p, 0, 4, stream()));
   const i64 nwin_slots = bits2 ? ((i64)PBINS << bits2) : PBINS;
   if ((rc = part1.alloc(nlog * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
       (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
@@ -257,12 +262,14 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   PSG_HIP(psg::sync_stream());
   memcpy(&items, pinned_buf(3, 64), 8);
   if (items > 0) {
-    hipLaunchKernelGGL(hist_items_kernel, dim3((unsigned)items), dim3(PSG_WG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap);
+    hipLaunchKernelGGL(hist_items_kernel, dim3((unsigned)items), dim3(PSG_WG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
     PSG_HIP(hipGetLastError());
   }
   tm.stop();
-  PSG_HIP(psg::sync_stream());
+  int h_ovf = 0;
+  if ((rc = psg::copy_d2h(&h_ovf, ovf.p, 4))) return rc;
   if (ms) *ms = tm.ms();
+  if (h_ovf) { set_error("gap histogram: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
   return 0;
 }
 

@@ -867,9 +867,44 @@ extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym,
   return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, h_final_rank, stats, d_log, nlog);
 }
 
+static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
+                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
+                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out);
+
+// A pass over a long tail is cut into chunks of at most 2^31 suffixes, streamed right to left with
+// the exact hand-over rank: bounds the rank log (8 + 8 GiB) and keeps every chunk in rank-log mode.
+#define PSG_PASS_CHUNK ((int64_t)1 << 31)
 static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out) {
+  int64_t chunk = PSG_PASS_CHUNK;
+  if (const char *e = getenv("PSG_PASS_CHUNK")) { int64_t v = atoll(e); if (v >= 64) chunk = v / 64 * 64; }   // tests
+  if (log_out || T <= chunk)
+    return stream_chunk(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, log_out, nlog_out);
+  psg_stream_stats acc = {};
+  int64_t fin = rank_at_end;
+  for (int64_t u_lo = 0; u_lo < T; u_lo += chunk) {     // u = distance from the tail end
+    int64_t u_hi = std::min<int64_t>(T, u_lo + chunk);
+    psg_stream_stats st = {};
+    // first chunk: the caller's context / start rank; later chunks start exactly where the previous one ended
+    int rc = stream_chunk(r, i0, last_sym, d_tail + (T - u_hi), u_hi - u_lo, u_lo == 0 ? ctx : 0,
+                          d_gt_in ? d_gt_in + ((u_lo + (u_lo == 0 ? 0 : ctx)) >> 5) : nullptr, u_lo == 0 ? rank_at_end : fin, d_gap,
+                          d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr, max_chains, &fin, &st, nullptr, nullptr);
+    if (rc) return rc;
+    acc.n_chains = std::max(acc.n_chains, st.n_chains); acc.chain_len = st.chain_len;
+    acc.warmup_steps = std::max(acc.warmup_steps, st.warmup_steps);
+    acc.unresolved += st.unresolved; acc.rounds += st.rounds;
+    acc.kernel_ms += st.kernel_ms; acc.total_ms += st.total_ms; acc.hist_ms += st.hist_ms;
+  }
+  note_kernel_ms(acc.kernel_ms);
+  if (h_final_rank) *h_final_rank = fin;
+  if (stats) *stats = acc;
+  return 0;
+}
+
+static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
+                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
+                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out) {
   PSG_REQUIRE(ctx >= 0 && (ctx & 63) == 0, "psg_stream_gap_ctx: right context must be a multiple of 64");
   PSG_REQUIRE(r && (d_gap || log_out), "psg_stream_gap: rank and gap required");
   PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");

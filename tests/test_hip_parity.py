@@ -148,6 +148,27 @@ def test_stream_gap_log_mode(A, kind, monkeypatch):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+@pytest.mark.parametrize("mode", ["atomic", "log"])
+def test_stream_gap_chunked_pass(A, monkeypatch, mode):
+    """long tails are streamed in chunks with exact hand-over ranks (PSG_PASS_CHUNK shrunk for the test)"""
+    monkeypatch.setenv("PSG_PASS_CHUNK", "4096")
+    monkeypatch.setenv("PSG_GAP_MODE", mode)
+    n = 60000
+    t = make_text("sig4z", n, 17)
+    b, e = 300, 9001
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m, T = e - b, n - e
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    d_gap = A.zeros(4 * (m + 2))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 16)
+    assert fin == want_fin and st.rounds >= (T + 4095) // 4096
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
 def test_stream_gap_overflow_checking_mode(A, monkeypatch):
     """the kernel variant used for tails of >= 2^32 suffixes (returning atomics + overflow flag)"""
     monkeypatch.setenv("PSG_GAP_MODE", "ovf")
