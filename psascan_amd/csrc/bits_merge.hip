@@ -24,8 +24,13 @@ __global__ __launch_bounds__(PSG_WG) void tile_sum_u32_kernel(const u32 *v, i64 
   __shared__ u64 scratch[8];
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u64 s = 0;
+  if (base + 8 <= n && ((uintptr_t)v & 15) == 0) {   // whole group: two 16-byte loads
+    uint4 a = *(const uint4 *)(v + base), b = *(const uint4 *)(v + base + 4);
+    s = (u64)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  } else {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) if (base + q < n) s += v[base + q];
+    for (int q = 0; q < 8; ++q) if (base + q < n) s += v[base + q];
+  }
   u64 tot = block_sum<u64>(s, scratch);
   if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
 }
@@ -92,8 +97,15 @@ __global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap,
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u32 g[8];
   u64 s = 0;
+  if (base + 8 <= m + 1 && ((uintptr_t)gap & 15) == 0) {
+    uint4 a = *(const uint4 *)(gap + base), b = *(const uint4 *)(gap + base + 4);
+    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { g[q] = base + q <= m ? gap[base + q] : 0; s += g[q]; }
+    for (int q = 0; q < 8; ++q) s += g[q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { g[q] = base + q <= m ? gap[base + q] : 0; s += g[q]; }
+  }
   u64 tot;
   u64 tp = tile_pref[blockIdx.x];
   u64 pre = tp + block_excl_scan<u64>(s, scratch, tot);

@@ -64,10 +64,11 @@ __device__ __forceinline__ u32 sm_eq_nibble(u32 w, u32 c4) {
 // One workgroup per segment of 4096 positions.  Entries are assembled in LDS and written out with
 // neighbouring lanes covering neighbouring entries of the same symbol (128-byte / 1-KiB runs):
 // a thread-per-symbol store pattern would issue 2 G fully divergent 16-byte stores for a 2 GiB BWT.
-struct SmListLds {                               // LIST phase (per half segment = 8 buckets of 256)
-  u32 cnt[8 * 256];
-  u8 pos[8 * 256 * SM_CAP];
-  uint4 out[256 * 8];                            // entry (symbol c, bucket j) at c*8 + j
+#define SM_NB 4              // LIST buckets handled per phase (4 phases per segment): 37 KiB LDS -> 4 workgroups per CU
+struct SmListLds {                               // LIST phase (SM_NB buckets of 256 positions)
+  u32 cnt[SM_NB * 256];
+  u8 pos[SM_NB * 256 * SM_CAP];
+  uint4 out[256 * SM_NB];                        // entry (symbol c, bucket j) at c*SM_NB + j
 };
 struct SmBitmapLds {                             // BITMAP phase (64 sub-buckets of 64)
   u64 bm[SM_MAX_BITMAP * 64];
@@ -97,13 +98,13 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   if (mymode == SM_BITMAP) { int k = atomicAdd(&nbm, 1); if (k < SM_MAX_BITMAP) bmSym[k] = (u8)c; }
   u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c]);
   const u32 c4 = (u32)c * 0x01010101u;
-  // ---------------- LIST symbols: two halves of 8 buckets ----------------
-  for (int half = 0; half < 2; ++half) {
-    for (int k = c; k < 8 * 256; k += 256) P.L.cnt[k] = 0;
-    for (int k = c; k < 8 * 256 * SM_CAP / 4; k += 256) ((u32 *)P.L.pos)[k] = 0xFFFFFFFFu;
+  // ---------------- LIST symbols: 16/SM_NB phases of SM_NB buckets ----------------
+  for (int ph = 0; ph < 16 / SM_NB; ++ph) {
+    for (int k = c; k < SM_NB * 256; k += 256) P.L.cnt[k] = 0;
+    for (int k = c; k < SM_NB * 256 * SM_CAP / 4; k += 256) ((u32 *)P.L.pos)[k] = 0xFFFFFFFFu;
     __syncthreads();
-    for (int j = 0; j < 8; ++j) {
-      int q = (half * 8 + j) * 256 + c;
+    for (int j = 0; j < SM_NB; ++j) {
+      int q = (ph * SM_NB + j) * 256 + c;
       if (base + q < m) {
         u32 s = sym[q];
         if ((u32)(t2S[s] >> SM_MODE_SHIFT) == SM_LIST) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
     }
     __syncthreads();
     if (mymode == SM_LIST) {
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < SM_NB; ++j) {
         u32 n = P.L.cnt[j * 256 + c];
         uint4 e;
         e.x = run;
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
           u32 idx = atomicAdd(pool_cursor, 1u);
           e.y = 0xFFu; e.z = idx; e.w = 0;
           if (idx < pool_cap) {
-            const u8 *bs = sym + (half * 8 + j) * 256;
-            i64 lim = m - (base + (half * 8 + j) * 256);
+            const u8 *bs = sym + (ph * SM_NB + j) * 256;
+            i64 lim = m - (base + (ph * SM_NB + j) * 256);
             for (int k = 0; k < 8; ++k) {
               u32 bits = 0;
               for (int w = 0; w < 8; ++w) bits |= sm_eq_nibble(((const u32 *)bs)[k * 8 + w], c4) << (4 * w);
@@ -138,15 +139,15 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
             }
           } else *err = 1;
         }
-        P.L.out[c * 8 + j] = e;
+        P.L.out[c * SM_NB + j] = e;
         run += n;
       }
     }
     __syncthreads();
-    for (int idx = c; idx < 256 * 8; idx += 256) {   // lanes 8k..8k+7 write 128 contiguous bytes of one symbol
-      int s = idx >> 3, j = idx & 7;
+    for (int idx = c; idx < 256 * SM_NB; idx += 256) {   // SM_NB consecutive lanes write consecutive entries of one symbol
+      int s = idx / SM_NB, j = idx % SM_NB;
       u64 ts = t2S[s];
-      i64 bk = seg * 16 + half * 8 + j;
+      i64 bk = seg * 16 + ph * SM_NB + j;
       if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST && bk * 256 < m) entries[(ts & SM_OFF_MASK) + bk] = P.L.out[idx];
     }
     __syncthreads();
