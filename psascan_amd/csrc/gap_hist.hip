@@ -21,11 +21,13 @@ using namespace psg;
 #define WSIZE (1 << WBITS)
 #define CAP (1 << 17)      // log entries per histogram work item
 #define PBINS 512          // bins per partition level
-#define PT 8192            // entries per partition tile
+#ifndef PT
+#define PT 16384           // entries per partition tile (runs of ~128 B per bin: full-line writes, tools/membench)
+#endif
 #define PNT 1024           // threads of a partition workgroup (8 entries per thread and tile)
 #define PAD 0xFFFFFFFFu
 
-struct Tile {              // LDS of one partition workgroup (~44 KiB -> 3 workgroups per CU)
+struct Tile {              // LDS of one partition workgroup (~76 KiB -> 2 workgroups per CU)
   u32 stage[PT];
   u32 h[PBINS];
   u32 loff[PBINS];

@@ -64,11 +64,11 @@ __device__ __forceinline__ u32 sm_eq_nibble(u32 w, u32 c4) {
 // One workgroup per segment of 4096 positions.  Entries are assembled in LDS and written out with
 // neighbouring lanes covering neighbouring entries of the same symbol (128-byte / 1-KiB runs):
 // a thread-per-symbol store pattern would issue 2 G fully divergent 16-byte stores for a 2 GiB BWT.
-#define SM_NB 4              // LIST buckets handled per phase (4 phases per segment): 37 KiB LDS -> 4 workgroups per CU
-struct SmListLds {                               // LIST phase (SM_NB buckets of 256 positions)
-  u32 cnt[SM_NB * 256];
-  u8 pos[SM_NB * 256 * SM_CAP];
-  uint4 out[256 * SM_NB];                        // entry (symbol c, bucket j) at c*SM_NB + j
+#define SM_NB 8                                  // LIST buckets per phase: runs of 8 entries = one full 128-byte line per symbol
+#define SM_OUT_STRIDE (256 + 2)                  // padded so the (symbol, bucket) -> lane transpose reads conflict-free
+struct SmListLds {                               // LIST phase (SM_NB buckets of 256 positions), ~33 KiB -> 4 workgroups per CU
+  // slot (bucket j, symbol c): {count, 12 position bytes}; rewritten IN PLACE into the finished entry
+  uint4 slot[SM_NB * SM_OUT_STRIDE];
 };
 struct SmBitmapLds {                             // BITMAP phase (64 sub-buckets of 64)
   u64 bm[SM_MAX_BITMAP * 64];
@@ -100,30 +100,30 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   const u32 c4 = (u32)c * 0x01010101u;
   // ---------------- LIST symbols: 16/SM_NB phases of SM_NB buckets ----------------
   for (int ph = 0; ph < 16 / SM_NB; ++ph) {
-    for (int k = c; k < SM_NB * 256; k += 256) P.L.cnt[k] = 0;
-    for (int k = c; k < SM_NB * 256 * SM_CAP / 4; k += 256) ((u32 *)P.L.pos)[k] = 0xFFFFFFFFu;
+    for (int k = c; k < SM_NB * SM_OUT_STRIDE; k += 256) P.L.slot[k] = make_uint4(0u, ~0u, ~0u, ~0u);
     __syncthreads();
     for (int j = 0; j < SM_NB; ++j) {
       int q = (ph * SM_NB + j) * 256 + c;
       if (base + q < m) {
         u32 s = sym[q];
         if ((u32)(t2S[s] >> SM_MODE_SHIFT) == SM_LIST) {
-          u32 slot = atomicAdd(&P.L.cnt[j * 256 + s], 1u);
-          if (slot < SM_CAP) P.L.pos[(j * 256 + s) * SM_CAP + slot] = (u8)c;   // position inside the bucket = c
+          uint4 *sl = &P.L.slot[j * SM_OUT_STRIDE + s];
+          u32 k = atomicAdd(&sl->x, 1u);
+          if (k < SM_CAP) ((u8 *)sl)[4 + k] = (u8)c;   // position inside the bucket = c
         }
       }
     }
     __syncthreads();
     if (mymode == SM_LIST) {
       for (int j = 0; j < SM_NB; ++j) {
-        u32 n = P.L.cnt[j * 256 + c];
+        const uint4 raw = P.L.slot[j * SM_OUT_STRIDE + c];
+        const u32 n = raw.x;
         uint4 e;
         e.x = run;
         if (n <= SM_CAP) {
-          const u8 *p = P.L.pos + (j * 256 + c) * SM_CAP;
-          e.y = n | ((u32)p[0] << 8) | ((u32)p[1] << 16) | ((u32)p[2] << 24);
-          e.z = (u32)p[3] | ((u32)p[4] << 8) | ((u32)p[5] << 16) | ((u32)p[6] << 24);
-          e.w = (u32)p[7] | ((u32)p[8] << 8) | ((u32)p[9] << 16) | ((u32)p[10] << 24);
+          e.y = n | (raw.y << 8);
+          e.z = (raw.y >> 24) | (raw.z << 8);
+          e.w = (raw.z >> 24) | (raw.w << 8);
         } else {   // dense bucket: 256-bit bitmap in the overflow pool
           u32 idx = atomicAdd(pool_cursor, 1u);
           e.y = 0xFFu; e.z = idx; e.w = 0;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
             }
           } else *err = 1;
         }
-        P.L.out[c * SM_NB + j] = e;
+        P.L.slot[j * SM_OUT_STRIDE + c] = e;
         run += n;
       }
     }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
       int s = idx / SM_NB, j = idx % SM_NB;
       u64 ts = t2S[s];
       i64 bk = seg * 16 + ph * SM_NB + j;
-      if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST && bk * 256 < m) entries[(ts & SM_OFF_MASK) + bk] = P.L.out[idx];
+      if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST && bk * 256 < m) entries[(ts & SM_OFF_MASK) + bk] = P.L.slot[j * SM_OUT_STRIDE + s];
     }
     __syncthreads();
   }

@@ -615,7 +615,7 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
     bool bitmap = (double)h[c] * 256.0 > 3.0 * (double)m;
     u64 nbk = bitmap ? (u64)cdiv(m, 64) : (u64)cdiv(m, 256);
     t2[c] = off16 | ((u64)(bitmap ? SM_BITMAP : SM_LIST) << SM_MODE_SHIFT);
-    off16 += nbk;
+    off16 += (nbk + 7) / 8 * 8;   // regions start on 128-byte lines (the fill kernel writes whole lines)
   }
   const i64 entries_bytes = (i64)off16 * 16;
   const u32 pool_cap = (u32)std::max<i64>(1024, m / 512);   // 32-byte bitmaps for dense LIST buckets

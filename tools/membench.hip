@@ -70,6 +70,25 @@ __global__ __launch_bounds__(256) void atomic_kernel(uint32_t *cnt, size_t ncnt,
   for (int t = 0; t < steps; ++t) { s = mix(s); atomicAdd(&cnt[s % ncnt], 1u); }
 }
 
+__global__ __launch_bounds__(256) void stream_write_kernel(uint4 *p, size_t n16) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x)
+    p[k] = make_uint4((uint32_t)k, 1, 2, 3);
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *p, uint4 *q, size_t n16) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) q[k] = p[k];
+}
+// the write shape of a radix partition / symbol-major fill: every workgroup owns 512 output streams
+// far apart and appends one run of R16 x 16 bytes to each of them per round
+template <int R16>
+__global__ __launch_bounds__(256) void runs_write_kernel(uint4 *p, size_t n16) {
+  const size_t G = gridDim.x, S = 512, chunk16 = n16 / (G * S);
+  for (size_t it = 0; it + R16 <= chunk16; it += R16)
+    for (size_t sb = 0; sb < S; sb += 256 / R16) {
+      size_t st = sb + threadIdx.x / R16;
+      p[(st * G + blockIdx.x) * chunk16 + it + threadIdx.x % R16] = make_uint4((uint32_t)it, 1, 2, 3);
+    }
+}
+
 template <class F> static double time_ms(F f, int reps = 3) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
@@ -91,6 +110,22 @@ int main(int argc, char **argv) {
   printf("table %.1f GiB, counters %.1f GiB\n", tab_gib, cnt_gib);
   double ms = time_ms([&] { hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0, 0, tab, n16, sink); });
   printf("streaming read            : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL(stream_write_kernel, dim3(256 * 16), dim3(256), 0, 0, tab, n16); });
+  printf("streaming write           : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, 0, tab, tab + n16 / 2, n16 / 2); });
+  printf("streaming copy (r+w bytes): %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((runs_write_kernel<2>), dim3(2048), dim3(256), 0, 0, tab, n16); });
+  printf("512-stream runs of   32 B : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((runs_write_kernel<4>), dim3(2048), dim3(256), 0, 0, tab, n16); });
+  printf("512-stream runs of   64 B : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((runs_write_kernel<8>), dim3(2048), dim3(256), 0, 0, tab, n16); });
+  printf("512-stream runs of  128 B : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((runs_write_kernel<16>), dim3(2048), dim3(256), 0, 0, tab, n16); });
+  printf("512-stream runs of  256 B : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((runs_write_kernel<64>), dim3(2048), dim3(256), 0, 0, tab, n16); });
+  printf("512-stream runs of 1024 B : %8.1f GB/s\n", tab_bytes / ms / 1e6);
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, tab, n16);
+  CK(hipDeviceSynchronize());
   const int steps = 512;
   const size_t lanes = 256ull * 32 * 64;   // 8 waves/SIMD on 256 CUs
   const int grid = (int)(lanes / 256);
