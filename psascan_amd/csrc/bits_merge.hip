@@ -60,7 +60,15 @@ static int fill_ones(u32 *d_bv, i64 nbits) {
   return 0;
 }
 
-__device__ __forceinline__ void clear_bit(u32 *bv, i64 pos) { atomicAnd(&bv[pos >> 5], ~(1u << (pos & 31))); }
+// explicit address spaces: when an LDS and a global atomic sit in the two arms of a branch the
+// compiler merges them into ONE flat atomic on a selected pointer, which is slower for both
+__device__ __forceinline__ void global_and(u32 *p, u32 x) {
+  (void)__hip_atomic_fetch_and((__attribute__((address_space(1))) u32 *)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_and(u32 *p, u32 x) {
+  (void)__hip_atomic_fetch_and((__attribute__((address_space(3))) u32 *)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void clear_bit(u32 *bv, i64 pos) { global_and(&bv[pos >> 5], ~(1u << (pos & 31))); }
 
 // =======================================================================================
 // K3: gap -> bitvector
@@ -81,13 +89,13 @@ __device__ __forceinline__ void bw_init(BitWindow &W, i64 first_pos) {
 }
 __device__ __forceinline__ void bw_clear(BitWindow &W, u32 *bv, i64 pos) {
   i64 k = (pos >> 5) - W.base_word;
-  if (k >= 0 && k < BMW) atomicAnd(&W.w[k], ~(1u << (pos & 31)));
+  if (k >= 0 && k < BMW) lds_and(&W.w[k], ~(1u << (pos & 31)));
   else clear_bit(bv, pos);
 }
 __device__ __forceinline__ void bw_flush(BitWindow &W, u32 *bv) {
   for (int k = threadIdx.x; k < BMW; k += PSG_WG) {
     u32 x = W.w[k];
-    if (x != 0xFFFFFFFFu) atomicAnd(&bv[W.base_word + k], x);
+    if (x != 0xFFFFFFFFu) global_and(&bv[W.base_word + k], x);
   }
 }
 
@@ -494,87 +502,171 @@ struct psg_merge_plan {
   std::vector<void *> owned;
 };
 
-__global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out) {
-  __shared__ u32 scratch[8];
-  __shared__ u16 cur[2][TILE_B];
-  __shared__ u32 vlo[TILE_B];
-  __shared__ u8 vhi[TILE_B];
-  i64 x0 = out_begin + (i64)blockIdx.x * TILE_B;
-  int len = (int)std::min<i64>(TILE_B, out_begin + count - x0);
-  i64 q0 = x0;
-  int cnt = len, s = 0;
-  bool identity = true;
-  int e0 = threadIdx.x * 16;
-  for (int h = 0; h < H && cnt > 0; ++h) {
-    MergeLevel Lh = lv[h];
-    if (h == H - 1) {
-      for (int i = threadIdx.x; i < cnt; i += PSG_WG) {
-        int slot = identity ? i : cur[s][i];
-        i64 idx = q0 + i;
-        u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
-        vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
-      }
-      break;
-    }
-    i64 nwords = (Lh.nbits + 31) >> 5;
-    // ones before q0 = sample + partial popcount inside the group
-    i64 g = q0 >> 12, gbase = g << 12;
-    u32 part = 0;
-    if (threadIdx.x < 128) {
-      i64 wb = gbase + (i64)threadIdx.x * 32;
-      if (wb < q0) {
-        u32 w = lv[h].mbv[wb >> 5];
-        i64 nb = q0 - wb;
-        if (nb < 32) w &= (1u << nb) - 1u;
-        part = __popc(w);
-      }
-    }
-    u32 part_tot = block_sum<u32>(part, scratch);
-    i64 ones_q0 = (i64)Lh.samp[g] + part_tot;
-    i64 zeros_q0 = q0 - ones_q0;
-    int n = std::max(0, std::min(16, cnt - e0));
-    u32 bits = n > 0 ? get_bits(Lh.mbv, q0 + e0, n, nwords) : 0;
-    u32 tot1;
-    u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
-    int z = e0 - (int)o;
-    // survivors (bit 1) are compacted to the front of the other buffer, own elements (bit 0) to its
-    // back, so that BOTH are then handled by coalesced loops (own element i <-> PSA index zeros_q0 + i)
-    for (int q = 0; q < n; ++q) {
-      int slot = identity ? e0 + q : cur[s][e0 + q];
-      int below = __popc(bits & ((1u << q) - 1u));
-      if ((bits >> q) & 1u) cur[s ^ 1][o + below] = (u16)slot;
-      else cur[s ^ 1][TILE_B - 1 - (z + q - below)] = (u16)slot;
-    }
-    __syncthreads();
-    int nown = cnt - (int)tot1;
-    for (int i = threadIdx.x; i < nown; i += PSG_WG) {
-      int slot = cur[s ^ 1][TILE_B - 1 - i];
-      i64 idx = zeros_q0 + i;
-      u64 v = (u64)Lh.beg + Lh.lo[idx] + (Lh.hi ? ((u64)Lh.hi[idx] << 32) : 0);
+#ifndef MT
+#define MT 2048
+#endif
+//#define MT 2048                 // output slots per merge tile: 18 KiB of LDS -> 8 workgroups per CU (a tile is a chain of
+#define MEPT (MT / PSG_WG)      // dependent loads, so the kernel is latency-bound: residency matters more than tile size)
+
+// PSA values of a contiguous range [first, first+cnt), cnt <= MT: eight independent loads per thread
+template <bool HI>
+__device__ __forceinline__ void merge_load(const MergeLevel &L, i64 first, int cnt, u32 (&lo)[MEPT], u32 (&hi)[MEPT]) {
+  const u32 *plo = L.lo + first + threadIdx.x;
+  const u8 *phi = L.hi + first + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < MEPT; ++u) {
+    int i = u * PSG_WG + threadIdx.x;
+    lo[u] = i < cnt ? gload(plo + u * PSG_WG) : 0;
+    if (HI) hi[u] = (i < cnt && L.hi) ? gload(phi + u * PSG_WG) : 0;
+  }
+}
+// element i goes to output slot slots[dir * i] (slot i when slots is null)
+template <bool HI>
+__device__ __forceinline__ void merge_scatter(i64 beg, int cnt, const u32 (&lo)[MEPT], const u32 (&hi)[MEPT], const u16 *slots, int dir,
+                                              u32 *vlo, u8 *vhi) {
+#pragma unroll
+  for (int u = 0; u < MEPT; ++u) {
+    int i = u * PSG_WG + threadIdx.x;
+    if (i < cnt) {
+      int slot = slots ? slots[dir * i] : i;
+      u64 v = (u64)beg + lo[u] + (HI ? ((u64)hi[u] << 32) : 0);
       vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
     }
+  }
+}
+// everything a level needs from memory for the range [q0, q0+cnt) of its merge bitvector: the
+// thread's MEPT bits, its share of the partial popcount in front of q0, the group's rank sample
+__device__ __forceinline__ void merge_level_loads(const MergeLevel &L, i64 q0, int cnt, u32 &bits, u32 &part, i64 &samp) {
+  const i64 nwords = (L.nbits + 31) >> 5;
+  const i64 g = q0 >> 12, gbase = g << 12;
+  part = 0;
+  if (threadIdx.x < 128) {
+    i64 wb = gbase + (i64)threadIdx.x * 32;
+    if (wb < q0) {
+      u32 w = gload(L.mbv + (wb >> 5));
+      i64 nb = q0 - wb;
+      if (nb < 32) w &= (1u << nb) - 1u;
+      part = __popc(w);
+    }
+  }
+  const int e0 = threadIdx.x * MEPT;
+  int n = std::max(0, std::min(MEPT, cnt - e0));
+  bits = n > 0 ? get_bits(L.mbv, q0 + e0, n, nwords) : 0;
+  samp = (i64)gload(L.samp + g);
+}
+
+// Persistent workgroups, software-pipelined so that a tile exposes as few dependent memory
+// latencies as possible: the loads of the NEXT level (its bits, or its PSA values when it is the
+// last one) are issued together with this level's own PSA loads, and the first level of the next
+// tile is requested before this tile is packed and stored.
+// HI: some half-block has a high byte plane (texts of 4 GiB and more)
+template <bool HI>
+#ifndef MWAVES
+#define MWAVES 4
+#endif
+__global__ __launch_bounds__(PSG_WG, MWAVES) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out, i64 ntiles) {
+  __shared__ u32 scratch[8];
+  __shared__ __attribute__((aligned(16))) u16 cur[2][MT];
+  __shared__ u32 vlo[MT];
+  __shared__ u8 vhi[MT];
+  const int e0 = threadIdx.x * MEPT;
+  const MergeLevel L0 = lv[0];
+  u32 bits = 0, part = 0;
+  i64 samp = 0;
+  i64 tile = blockIdx.x;
+  if (tile < ntiles && H > 1) {
+    i64 x0 = out_begin + tile * MT;
+    merge_level_loads(L0, x0, (int)std::min<i64>(MT, out_begin + count - x0), bits, part, samp);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const i64 x0 = out_begin + tile * MT;
+    const int len = (int)std::min<i64>(MT, out_begin + count - x0);
+    i64 q0 = x0;
+    int cnt = len, s = 0;
+    bool identity = true;
+    MergeLevel Lh = L0;
+    u32 lo[MEPT], hi[MEPT], lo2[MEPT], hi2[MEPT];
+    if (H == 1) {
+      merge_load<HI>(Lh, q0, cnt, lo, hi);
+      merge_scatter<HI>(Lh.beg, cnt, lo, hi, nullptr, 1, vlo, vhi);
+    } else {
+      for (int h = 0;; ++h) {   // invariant: h < H-1, cnt > 0, (bits, part, samp) loaded for (Lh, q0, cnt)
+        const MergeLevel Ln = lv[h + 1];
+        const bool next_last = h + 2 == H;
+        u32 part_tot = block_sum<u32>(part, scratch);
+        const i64 ones_q0 = samp + part_tot, zeros_q0 = q0 - ones_q0;
+        const int n = std::max(0, std::min(MEPT, cnt - e0));
+        u32 tot1;
+        const u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
+        const int nown = cnt - (int)tot1, ncnt = (int)tot1;
+        // every load that is addressable now: own elements of this level + the next level's input
+        merge_load<HI>(Lh, zeros_q0, nown, lo, hi);
+        u32 nbits = 0, npart = 0;
+        i64 nsamp = 0;
+        if (ncnt > 0) {
+          if (next_last) merge_load<HI>(Ln, ones_q0, ncnt, lo2, hi2);
+          else merge_level_loads(Ln, ones_q0, ncnt, nbits, npart, nsamp);
+        }
+        // survivors (bit 1) are compacted to the front of the other slot buffer, own elements (bit 0)
+        // to its back, so that both are handled by coalesced loops (own element i <-> PSA index zeros_q0 + i)
+        const int z = e0 - (int)o;
+        for (int q = 0; q < n; ++q) {
+          int slot = identity ? e0 + q : cur[s][e0 + q];
+          int below = __popc(bits & ((1u << q) - 1u));
+          if ((bits >> q) & 1u) cur[s ^ 1][o + below] = (u16)slot;
+          else cur[s ^ 1][MT - 1 - (z + q - below)] = (u16)slot;
+        }
+        __syncthreads();
+        merge_scatter<HI>(Lh.beg, nown, lo, hi, cur[s ^ 1] + MT - 1, -1, vlo, vhi);
+        if (ncnt == 0) break;
+        if (next_last) { merge_scatter<HI>(Ln.beg, ncnt, lo2, hi2, cur[s ^ 1], 1, vlo, vhi); break; }
+        __syncthreads();
+        q0 = ones_q0; cnt = ncnt; s ^= 1; identity = false;
+        Lh = Ln; bits = nbits; part = npart; samp = nsamp;
+      }
+    }
     __syncthreads();
-    q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
-  }
-  __syncthreads();
-  // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords per thread
-  u32 *o32 = (u32 *)(out + 5 * (x0 - out_begin));
-  int nq = len >> 2;
-  for (int g4 = threadIdx.x; g4 < nq; g4 += PSG_WG) {
-    int e = 4 * g4;
-    u32 l0 = vlo[e], l1 = vlo[e + 1], l2 = vlo[e + 2], l3 = vlo[e + 3];
-    u32 h0 = vhi[e], h1 = vhi[e + 1], h2 = vhi[e + 2], h3 = vhi[e + 3];
-    u32 *dst = o32 + 5 * g4;
-    dst[0] = l0;
-    dst[1] = h0 | (l1 << 8);
-    dst[2] = (l1 >> 24) | (h1 << 8) | (l2 << 16);
-    dst[3] = (l2 >> 16) | (h2 << 16) | (l3 << 24);
-    dst[4] = (l3 >> 8) | (h3 << 24);
-  }
-  u8 *o8 = out + 5 * (x0 - out_begin);
-  for (int bb = nq * 20 + threadIdx.x; bb < 5 * len; bb += PSG_WG) {   // ragged tail of the last tile
-    int e = bb / 5, rr = bb - 5 * e;
-    o8[bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
+    {   // request the first level of this workgroup's next tile before packing this one
+      i64 nt = tile + gridDim.x;
+      if (nt < ntiles && H > 1) {
+        i64 nx0 = out_begin + nt * MT;
+        merge_level_loads(L0, nx0, (int)std::min<i64>(MT, out_begin + count - nx0), bits, part, samp);
+      }
+    }
+    // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords, staged in LDS (the
+    // slot buffers are dead now) so that the tile leaves as whole 16-byte/256-byte coalesced stores
+    u32 *packed = (u32 *)&cur[0][0];                 // 8 KiB: half a tile (1024 entries = 5 KiB) at a time
+    u8 *obase = out + 5 * (x0 - out_begin);
+    const bool al16 = ((uintptr_t)obase & 15) == 0;
+    for (int eb = 0; eb < len; eb += MT / 2) {
+      const int ne = std::min(MT / 2, len - eb), nq = ne >> 2;
+      if (eb) __syncthreads();
+      for (int g4 = threadIdx.x; g4 < nq; g4 += PSG_WG) {
+        int e = eb + 4 * g4;
+        u32 l0 = vlo[e], l1 = vlo[e + 1], l2 = vlo[e + 2], l3 = vlo[e + 3];
+        u32 h0 = vhi[e], h1 = vhi[e + 1], h2 = vhi[e + 2], h3 = vhi[e + 3];
+        u32 *dst = packed + 5 * g4;
+        dst[0] = l0;
+        dst[1] = h0 | (l1 << 8);
+        dst[2] = (l1 >> 24) | (h1 << 8) | (l2 << 16);
+        dst[3] = (l2 >> 16) | (h2 << 16) | (l3 << 24);
+        dst[4] = (l3 >> 8) | (h3 << 24);
+      }
+      __syncthreads();
+      u32 *dst = (u32 *)(obase + 5 * eb);            // 5 * 1024 bytes per half: keeps the 16-byte alignment
+      const int ndw = nq * 5;
+      if (al16) {
+        for (int k = threadIdx.x; k < (ndw >> 2); k += PSG_WG) ((uint4 *)dst)[k] = ((const uint4 *)packed)[k];
+        for (int k = (ndw & ~3) + threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
+      } else {
+        for (int k = threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
+      }
+      for (int bb = nq * 20 + threadIdx.x; bb < 5 * ne; bb += PSG_WG) {   // ragged tail of the last tile
+        int e = eb + bb / 5, rr = bb % 5;
+        obase[5 * eb + bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
+      }
+    }
+    __syncthreads();   // vlo/vhi/cur are reused by the next tile
   }
 }
 
@@ -634,7 +726,17 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
   PSG_REQUIRE(((uintptr_t)d_out & 3) == 0, "psg_merge_run: output must be 4-byte aligned");
   if (out_count == 0) return 0;
   EventTimer tm; tm.start();
-  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)cdiv(out_count, TILE_B)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
+  const i64 ntiles = cdiv(out_count, MT);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  bool any_hi = false;
+  for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
+  auto kern = any_hi ? merge_kernel<true> : merge_kernel<false>;
+  int per_cu = 0;   // persistent grid = what is resident at once
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PSG_WG, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+  const unsigned grid = (unsigned)std::min<i64>(ntiles, (i64)cus * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out, ntiles);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());

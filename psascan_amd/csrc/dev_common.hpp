@@ -139,13 +139,25 @@ template <class T> __device__ __forceinline__ T block_sum(T v, T *scratch) {
   return tot;
 }
 
+// Load through a pointer whose address space the compiler cannot see (rebuilt from an integer, or
+// read from a descriptor in memory).  Forces global_load: a flat_load also counts against lgkmcnt,
+// so every wait for an LDS access would wait for the outstanding global loads as well.
+template <class T> __device__ __forceinline__ T gload(const T *p) {
+  return *(const __attribute__((address_space(1))) T *)p;
+}
+typedef unsigned int psg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gload(const uint4 *p) {
+  psg_u32x4 v = *(const __attribute__((address_space(1))) psg_u32x4 *)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // bits [pos, pos+cnt) (cnt <= 32) of an LSB-first u32 bit array; reads at most words
 // pos/32 and pos/32+1 (the second only if needed and < nwords).
 __device__ __forceinline__ u32 get_bits(const u32 *bv, i64 pos, int cnt, i64 nwords) {
   i64 w = pos >> 5;
   int sh = (int)(pos & 31);
-  u64 lo = bv[w];
-  u64 hi = (sh + cnt > 32 && w + 1 < nwords) ? bv[w + 1] : 0;
+  u64 lo = gload(bv + w);   // bit arrays always live in HBM
+  u64 hi = (sh + cnt > 32 && w + 1 < nwords) ? gload(bv + w + 1) : 0;
   u64 x = (lo | (hi << 32)) >> sh;
   return cnt >= 32 ? (u32)x : (u32)x & ((1u << cnt) - 1u);
 }

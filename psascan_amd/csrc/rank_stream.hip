@@ -425,9 +425,9 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
       c.last_addr = (uintptr_t)(P.tail + (P.T - c.u1));   // address of the last byte this chain needs
       c.cp = (const uint4 *)(addr & ~(uintptr_t)15);
       c.tcnt = (int)(addr & 15) + 1;                       // bytes left in the current chunk
-      uint4 cur = *c.cp;
+      uint4 cur = gload(c.cp);
       c.nxt = cur;
-      if ((uintptr_t)c.cp > c.last_addr) c.nxt = *(c.cp - 1);
+      if ((uintptr_t)c.cp > c.last_addr) c.nxt = gload(c.cp - 1);
       c.tlo = (u64)cur.x | ((u64)cur.y << 32);
       c.thi = (u64)cur.z | ((u64)cur.w << 32);
       int sh = (16 - c.tcnt) * 8;                          // bring byte (tcnt-1) of the chunk to the top
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
             c.tlo = (u64)c.nxt.x | ((u64)c.nxt.y << 32);
             c.thi = (u64)c.nxt.z | ((u64)c.nxt.w << 32);
             --c.cp;
-            if ((uintptr_t)c.cp > c.last_addr) c.nxt = *(c.cp - 1);
+            if ((uintptr_t)c.cp > c.last_addr) c.nxt = gload(c.cp - 1);
           }
         }
       }
