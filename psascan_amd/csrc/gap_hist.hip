@@ -68,7 +68,7 @@ __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, 
   u32 pre = part_scan(hb, S.scratch, tot);
   if (threadIdx.x < PBINS) {
     S.loff[threadIdx.x] = pre;
-    S.gbase[threadIdx.x] = S.cur[threadIdx.x];
+    S.gbase[threadIdx.x] = S.cur[threadIdx.x] - pre;   // staged slot s of this bin goes to out[gbase + s]
     S.cur[threadIdx.x] += hb;
   }
   __syncthreads();
@@ -84,7 +84,7 @@ __device__ __forceinline__ void scatter_tile(Tile &S, const u32 *keys, i64 beg, 
   for (u32 s = threadIdx.x; s < tot; s += PNT) {
     u32 x = S.stage[s];
     u32 bin = (x >> shift) & mask;
-    out[S.gbase[bin] + (s - S.loff[bin])] = x;
+    out[S.gbase[bin] + s] = x;
   }
   __syncthreads();
 }
