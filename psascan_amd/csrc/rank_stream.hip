@@ -387,19 +387,48 @@ struct StreamParams {
 //       rank loads in flight (memory-level parallelism beyond what 8 waves per SIMD give).
 struct Chain {
   i64 i, k, u0, u1, w;
-  u64 thi, tlo;
-  int tcnt;
-  const uint4 *cp;
-  uint4 nxt;
+  u64 thi, tlo;       // current 16-byte text chunk, next byte on top
+  int tcnt;           // bytes left in it
+  int nbuf;           // chunks still buffered in b0..b2 (b0 is next)
+  uint4 b0, b1, b2;   // rest of the current 64-byte text block: ONE memory access per 64 steps (every private
+  const uint4 *bp;    // 16-byte load of a chain costs a full random HBM access, ~like a rank load)
   uintptr_t last_addr;
   u32 gin, gin_next, gout;
 };
+
+// the 64-byte text block at bp; its 16-byte chunks are consumed in descending order starting with chunk
+// `first`: cur = that chunk, b0.. = the following ones
+struct TextBlock { uint4 cur, b0, b1, b2; };
+__device__ __forceinline__ TextBlock load_text_block(const uint4 *bp, int first) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  uint4 x0 = gload(bp), x1 = z, x2 = z, x3 = z;
+  if (first >= 1) x1 = gload(bp + 1);
+  if (first >= 2) x2 = gload(bp + 2);
+  if (first >= 3) x3 = gload(bp + 3);
+  TextBlock t;
+  t.cur = first == 3 ? x3 : (first == 2 ? x2 : (first == 1 ? x1 : x0));
+  t.b0 = first == 3 ? x2 : (first == 2 ? x1 : x0);
+  t.b1 = first == 3 ? x1 : x0;
+  t.b2 = x0;
+  return t;
+}
+#define PSG_TEXT_BLOCK(c, first_)                                \
+  do {                                                           \
+    const int f_ = (first_);                                     \
+    const TextBlock tb_ = load_text_block((c).bp, f_);           \
+    (c).b0 = tb_.b0; (c).b1 = tb_.b1; (c).b2 = tb_.b2;           \
+    (c).nbuf = f_;                                               \
+    (c).tlo = (u64)tb_.cur.x | ((u64)tb_.cur.y << 32);           \
+    (c).thi = (u64)tb_.cur.z | ((u64)tb_.cur.w << 32);           \
+  } while (0)
 
 template <int CNT, int B, int MODE, int CPL>
 __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
   constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
   __shared__ u32 lstage[MODE == 2 ? CPL * 4 * PSG_WG : 1];
+  __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
+  const bool gt16 = P.gt_out && ((uintptr_t)P.gt_out & 15) == 0 && (P.L & 127) == 0;
   load_tables(lds, P.g_T1, P.g_tot, P.nsb);
   const u64 *T1 = lds, *tot = lds + P.nsb * 256;
   const i64 nlanes = (P.nchains + CPL - 1) / CPL;
@@ -417,19 +446,16 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
     c.i = act ? P.init[c.k] : 0;
     c.w = c.u0 >> 5;
     c.gin = 0; c.gin_next = 0; c.gout = 0;
-    c.tcnt = 1; c.thi = 0; c.tlo = 0; c.cp = nullptr; c.last_addr = 0; c.nxt = make_uint4(0, 0, 0, 0);
+    c.tcnt = 1; c.thi = 0; c.tlo = 0; c.bp = nullptr; c.last_addr = 0; c.nbuf = 0;
+    c.b0 = make_uint4(0, 0, 0, 0); c.b1 = c.b0; c.b2 = c.b0;
     if (act) {
       // text cursor: descending bytes starting at tail[T-1-u0], consumed from a 128-bit shift
       // register (no dynamically indexed registers: hipcc would spill those to scratch memory)
       uintptr_t addr = (uintptr_t)(P.tail + (P.T - 1 - c.u0));
       c.last_addr = (uintptr_t)(P.tail + (P.T - c.u1));   // address of the last byte this chain needs
-      c.cp = (const uint4 *)(addr & ~(uintptr_t)15);
+      c.bp = (const uint4 *)(addr & ~(uintptr_t)63);
       c.tcnt = (int)(addr & 15) + 1;                       // bytes left in the current chunk
-      uint4 cur = gload(c.cp);
-      c.nxt = cur;
-      if ((uintptr_t)c.cp > c.last_addr) c.nxt = gload(c.cp - 1);
-      c.tlo = (u64)cur.x | ((u64)cur.y << 32);
-      c.thi = (u64)cur.z | ((u64)cur.w << 32);
+      PSG_TEXT_BLOCK(c, (int)((addr >> 4) & 3));
       int sh = (16 - c.tcnt) * 8;                          // bring byte (tcnt-1) of the chunk to the top
       if (sh >= 64) { c.thi = c.tlo << (sh - 64); c.tlo = 0; }
       else if (sh > 0) { c.thi = (c.thi << sh) | (c.tlo >> (64 - sh)); c.tlo <<= sh; }
@@ -490,10 +516,15 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
           }
           if (--c.tcnt == 0) {
             c.tcnt = 16;
-            c.tlo = (u64)c.nxt.x | ((u64)c.nxt.y << 32);
-            c.thi = (u64)c.nxt.z | ((u64)c.nxt.w << 32);
-            --c.cp;
-            if ((uintptr_t)c.cp > c.last_addr) c.nxt = gload(c.cp - 1);
+            if (c.nbuf > 0) {
+              --c.nbuf;
+              c.tlo = (u64)c.b0.x | ((u64)c.b0.y << 32);
+              c.thi = (u64)c.b0.z | ((u64)c.b0.w << 32);
+              c.b0 = c.b1; c.b1 = c.b2;
+            } else if ((uintptr_t)c.bp > c.last_addr) {    // the chain needs bytes below this block
+              c.bp -= 4;
+              PSG_TEXT_BLOCK(c, 3);
+            }
           }
         }
       }
@@ -502,7 +533,23 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
     for (int q = 0; q < CPL; ++q) {
       if (steps[q]) {
         Chain &c = S[q];
-        if (P.gt_out) P.gt_out[c.w - (P.ctx >> 5)] = c.gout;
+        if (P.gt_out) {
+          // scattered 4-byte stores are read-modify-writes of a whole sector in HBM (5 ms of a 57 ms pass):
+          // stage the words in lane-private LDS slots and write 16 aligned bytes per 128 steps
+          const int grp = (int)(g >> 5) & 3;
+          u32 *gs = gstage + q * 4 * PSG_WG;
+          const i64 wi = c.w - (P.ctx >> 5);
+          if (!gt16) P.gt_out[wi] = c.gout;
+          else {
+            gs[grp * PSG_WG + threadIdx.x] = c.gout;
+            const bool last_group = c.u0 + g + 32 >= c.u1;
+            if (grp == 3) {
+              *(uint4 *)(P.gt_out + (wi - 3)) = make_uint4(gs[threadIdx.x], gs[PSG_WG + threadIdx.x], gs[2 * PSG_WG + threadIdx.x], c.gout);
+            } else if (last_group) {
+              for (int j = 0; j <= grp; ++j) P.gt_out[wi - grp + j] = gs[j * PSG_WG + threadIdx.x];
+            }
+          }
+        }
         c.gin = c.gin_next;
         ++c.w;
         if (MODE == 2 && (steps[q] & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
@@ -943,7 +990,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     if (blocks > 8) blocks = 8;
     Ktarget = (i64)blocks * cus * PSG_WG * cpl;
   }
-  i64 L = cdiv(cdiv(T, Ktarget), 64) * 64;
+  i64 L = cdiv(cdiv(T, Ktarget), 128) * 128;   // multiple of 128: a chain's gt_out words start on a 16-byte boundary
   i64 K = cdiv(T, L);
   st.n_chains = K; st.chain_len = L;
   DevBuf lo_d, hi_d, fin_d, list_d, flag_d;

@@ -64,6 +64,24 @@ __global__ __launch_bounds__(256) void shape_kernel(const uint4 *tab, size_t nro
   if (acc == 0x12345678) *sink = acc;
 }
 
+// the stream kernel's full memory shape: one dependent random 16-byte load per step, one coalesced
+// 16-byte log store per 4 steps (LOG), one private streaming 16-byte load per 16 steps (TEXT)
+template <bool LOG, bool TEXT>
+__global__ __launch_bounds__(256) void shape2_kernel(const uint4 *tab, size_t nrows, uint4 *log, const uint4 *text, int steps, uint32_t *sink) {
+  const size_t lanes = (size_t)gridDim.x * 256, lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t s = mix(lane);
+  uint32_t acc = 0;
+  for (int t = 0; t < steps; ++t) {
+    uint4 v = tab[(s % nrows) * 68];
+    uint32_t x = v.x;
+    if (TEXT && (t & 15) == 0) { uint4 w = text[lane * (size_t)(steps / 16) + (t >> 4)]; x ^= w.z; }
+    acc += x;
+    s = mix(s ^ x);
+    if (LOG && (t & 3) == 3) log[(size_t)(t >> 2) * lanes + lane] = make_uint4(x, acc, (uint32_t)s, t);
+  }
+  if (acc == 0x12345678) *sink = acc;
+}
+
 template <int U>
 __global__ __launch_bounds__(256) void atomic_kernel(uint32_t *cnt, size_t ncnt, int steps) {
   uint64_t s = mix((uint64_t)blockIdx.x * 256 + threadIdx.x);
@@ -133,8 +151,25 @@ int main(int argc, char **argv) {
   size_t nrows = n16 / 68;
   ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, false, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
   printf("dependent random loads x1 : %8.2f G steps/s  (%.1f ns/step/lane)\n", lanes * steps / ms / 1e6, ms * 1e6 / steps);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, false, 1>), dim3(grid), dim3(256), 0, 0, tab, n16, cnt, cnt_bytes / 4, steps, sink); });
+  printf("  same, any 16-byte slot  : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, false, 4>), dim3(grid), dim3(256), 0, 0, tab, n16 / 4, cnt, cnt_bytes / 4, steps, sink); });
+  printf("  same, 64-byte aligned   : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, false, 8>), dim3(grid), dim3(256), 0, 0, tab, n16 / 8, cnt, cnt_bytes / 4, steps, sink); });
+  printf("  same, 128-byte aligned  : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
   ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<2, false, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
   printf("dependent random loads x2 : %8.2f G steps/s  (%.1f ns/step/lane)\n", lanes * steps / ms / 1e6, ms * 1e6 / steps);
+  {
+    uint4 *logb = (uint4 *)cnt;                              // 8 GiB: lanes * steps/4 * 16 B = 1 GiB used
+    const uint4 *text = tab + n16 / 2;                       // lanes * steps/16 * 16 B = 256 MiB used
+    ms = time_ms([&] { hipLaunchKernelGGL((shape2_kernel<true, false>), dim3(grid), dim3(256), 0, 0, tab, nrows / 2, logb, text, steps, sink); });
+    printf("random load + log store/4 : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL((shape2_kernel<false, true>), dim3(grid), dim3(256), 0, 0, tab, nrows / 2, logb, text, steps, sink); });
+    printf("random load + text/16     : %8.2f G steps/s\n", lanes * steps / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL((shape2_kernel<true, true>), dim3(grid), dim3(256), 0, 0, tab, nrows / 2, logb, text, steps, sink); });
+    printf("random load + log + text  : %8.2f G steps/s   <- stream kernel (symbol-major, rank log)\n", lanes * steps / ms / 1e6);
+    CK(hipMemset(cnt, 0, cnt_bytes));
+  }
   ms = time_ms([&] { hipLaunchKernelGGL((atomic_kernel<1>), dim3(grid), dim3(256), 0, 0, cnt, cnt_bytes / 4, steps); });
   printf("random u32 atomics        : %8.2f G atomics/s\n", lanes * steps / ms / 1e6);
   ms = time_ms([&] { hipLaunchKernelGGL((chase_kernel<1, true, 68>), dim3(grid), dim3(256), 0, 0, tab, nrows, cnt, cnt_bytes / 4, steps, sink); });
