@@ -1037,16 +1037,18 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   std::vector<i64> ready;
   while (ndone < K) {
     ready.clear();
-    for (i64 k = 0; k < K; ++k)
-      if (!done[k] && (resolved[k] || (k > 0 && done[k - 1]))) {
-        if (!resolved[k]) { lo[k] = fin[k - 1]; resolved[k] = 1; }
-        ready.push_back(k);
-      }
-    if (ready.empty()) { set_error("stream: no runnable chain (internal error)"); return PSG_ECHECK; }
+    const bool all_ready = nun == 0;   // the usual case: every start rank came out of the warm-up
+    if (!all_ready)
+      for (i64 k = 0; k < K; ++k)
+        if (!done[k] && (resolved[k] || (k > 0 && done[k - 1]))) {
+          if (!resolved[k]) { lo[k] = fin[k - 1]; resolved[k] = 1; }
+          ready.push_back(k);
+        }
+    if (!all_ready && ready.empty()) { set_error("stream: no runnable chain (internal error)"); return PSG_ECHECK; }
     if (nun > 0) {  // start ranks may have been patched on the host
       PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));
     }
-    if ((i64)ready.size() == K) { SP.list = nullptr; SP.nchains = K; }
+    if (all_ready || (i64)ready.size() == K) { SP.list = nullptr; SP.nchains = K; }
     else {
       if (int rc_ = psg::copy_h2d(list_d.p, ready.data(), (size_t)(ready.size() * 8))) return rc_;
       SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
@@ -1058,8 +1060,8 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     PSG_HIP(hipMemcpyAsync(fin, fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
     PSG_HIP(psg::sync_stream());
     kms += ktm.ms();
-    for (i64 k : ready) done[k] = 1;
-    ndone += (i64)ready.size();
+    if (all_ready) ndone = K;
+    else { for (i64 k : ready) done[k] = 1; ndone += (i64)ready.size(); }
     st.rounds++;
   }
   // invariant: the rank a chain ends with is the start rank of the next chain
