@@ -162,6 +162,187 @@ __global__ __launch_bounds__(PNT) void part_level2_kernel(const u32 *keys, const
   for (i64 beg = sb; beg < se; beg += PT) scatter_tile(S, keys, beg, std::min<i64>(beg + PT, se), WBITS, mask, out);
 }
 
+// ---------------------------------------------------------------------------------------
+// Partition, second version (used by gap_hist_from_log; psg_log_partition keeps the exact-size
+// scatter above).  What the first version gets wrong on this memory system (tools/membench):
+// a run of ~32 entries per bin and tile starts and ends in the middle of a 64-byte sector, and a
+// partially written sector costs a read-modify-write in HBM.  Here every workgroup keeps 32
+// staging slots per bin in LDS ACROSS its tiles and writes whole, aligned 16-entry units only;
+// the per-workgroup segment of a bin is rounded up to a multiple of 16 entries and the holes hold
+// the "no entry" value, which every consumer of the log already skips.
+// ---------------------------------------------------------------------------------------
+#define P2T 512            // threads per workgroup (2 workgroups per CU)
+#define P2TS 2048          // entries per tile
+#define P2C 32             // staging slots per bin
+#define P2U 16             // unit = 16 entries = one 64-byte sector
+#define P2SLACK ((i64)P2U * PBINS)   // rounding growth bound of one partition call per (workgroup | segment)
+
+struct Stage2 {            // ~71 KiB
+  u32 cnt[PBINS];
+  __attribute__((aligned(16))) u32 buf[PBINS][P2C];
+  u64 cur[PBINS];
+  u16 list[PBINS];
+  u32 nlist;
+  u32 scratch[P2T / 64];
+};
+
+__device__ __forceinline__ u32 p2_scan(u32 v, u32 *scratch, u32 &total) {   // exclusive scan over the P2T threads
+  u32 inc = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < P2T / 64; ++k) { u32 x = scratch[k]; if (k < w) base += x; tot += x; }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 *keys, i64 beg, i64 end, int shift, u32 mask, u32 *out) {
+  u32 v[P2TS / P2T];
+#pragma unroll
+  for (int j = 0; j < P2TS / P2T; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
+#pragma unroll
+  for (int j = 0; j < P2TS / P2T; ++j) {
+    if (v[j] == PAD) continue;
+    const u32 b = (v[j] >> shift) & mask;
+    const u32 slot = atomicAdd(&S.cnt[b], 1u);
+    if (slot < P2C) S.buf[b][slot] = v[j];
+    else out[atomicAdd((unsigned long long *)&S.cur[b], 1ull)] = v[j];   // bin full between two flushes: rare, written directly
+  }
+}
+
+// write out the complete units of every bin
+__device__ __forceinline__ void p2_flush(Stage2 &S, u32 *out) {
+  __syncthreads();
+  for (int b = threadIdx.x; b < PBINS; b += P2T) {
+    const u32 n = S.cnt[b] < P2C ? S.cnt[b] : P2C;
+    if (n >= P2U) S.list[atomicAdd(&S.nlist, 1u)] = (u16)b;
+    S.cnt[b] = n;
+  }
+  __syncthreads();
+  const u32 nl = S.nlist;
+  const int li = threadIdx.x & 3;
+  for (u32 f = threadIdx.x >> 2; f < nl; f += P2T / 4) {   // 4 lanes x 16 bytes = one unit
+    const u32 b = S.list[f], n = S.cnt[b];
+    const u64 pos = S.cur[b];
+    const uint4 lo = ((const uint4 *)S.buf[b])[li], hi = ((const uint4 *)S.buf[b])[4 + li];
+    const bool two = n >= P2C;                               // both units are complete
+    u32 *dst = out + pos;
+    if ((pos & 3) == 0) {
+      ((uint4 *)dst)[li] = lo;
+      if (two) ((uint4 *)dst)[4 + li] = hi;
+    } else {                                                 // cursor knocked off its alignment by a direct write
+      dst[4 * li] = lo.x; dst[4 * li + 1] = lo.y; dst[4 * li + 2] = lo.z; dst[4 * li + 3] = lo.w;
+      if (two) { dst[16 + 4 * li] = hi.x; dst[17 + 4 * li] = hi.y; dst[18 + 4 * li] = hi.z; dst[19 + 4 * li] = hi.w; }
+    }
+    if (!two) ((uint4 *)S.buf[b])[li] = hi;                  // entries 16.. move to the front (LDS accesses of a wave stay in order)
+    if (li == 0) { S.cnt[b] = two ? 0 : n - P2U; S.cur[b] = pos + (two ? 2 * P2U : P2U); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) S.nlist = 0;
+}
+
+// end of a workgroup's input: the leftovers (< one unit per bin after p2_flush), then "no entry" up to the
+// next unit boundary -- segments are whole units, so the written length is exactly the segment's
+__device__ __forceinline__ void p2_flush_final(Stage2 &S, u32 *out) {
+  p2_flush(S, out);
+  for (int b = threadIdx.x; b < PBINS; b += P2T) {
+    const u32 n = S.cnt[b];
+    u64 pos = S.cur[b];
+    for (u32 k = 0; k < n; ++k) out[pos++] = S.buf[b][k];
+    while (pos & (P2U - 1)) out[pos++] = PAD;
+    S.cur[b] = pos;
+    S.cnt[b] = 0;
+  }
+}
+
+// level 1, step A: workgroup g counts the entries of its chunk [g*chunk, (g+1)*chunk)
+__global__ __launch_bounds__(P2T) void p2_count_kernel(const u32 *keys, i64 n, i64 chunk, int shift, u32 *counts) {
+  __shared__ u32 h[PBINS];
+  for (int b = threadIdx.x; b < PBINS; b += P2T) h[b] = 0;
+  __syncthreads();
+  const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
+  for (i64 k0 = cb; k0 < ce; k0 += 8 * P2T) {
+    u32 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < ce ? keys[k] : PAD; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] >> shift], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < PBINS; b += P2T) counts[(i64)blockIdx.x * PBINS + b] = h[b];
+}
+
+// level 1, step B: off[g][b] = start of workgroup g's segment of bin b; segments are whole units
+__global__ __launch_bounds__(PBINS) void p2_offsets_kernel(const u32 *counts, int G, u64 *off, u64 *bin_base) {
+  __shared__ u64 tot[PBINS];
+  int b = threadIdx.x;
+  u64 t = 0;
+  for (int g = 0; g < G; ++g) t += (counts[(i64)g * PBINS + b] + (P2U - 1)) / P2U * P2U;
+  tot[b] = t;
+  __syncthreads();
+  if (b == 0) {
+    u64 run = 0;
+    for (int k = 0; k < PBINS; ++k) { u64 x = tot[k]; tot[k] = run; run += x; }
+    bin_base[PBINS] = run;
+  }
+  __syncthreads();
+  u64 run = tot[b];
+  bin_base[b] = run;
+  for (int g = 0; g < G; ++g) { off[(i64)g * PBINS + b] = run; run += (counts[(i64)g * PBINS + b] + (P2U - 1)) / P2U * P2U; }
+}
+
+// level 1, step C
+__global__ __launch_bounds__(P2T) void p2_scatter_kernel(const u32 *keys, i64 n, i64 chunk, int shift, const u64 *off, u32 *out) {
+  __shared__ Stage2 S;
+  for (int b = threadIdx.x; b < PBINS; b += P2T) { S.cur[b] = off[(i64)blockIdx.x * PBINS + b]; S.cnt[b] = 0; }
+  if (threadIdx.x == 0) S.nlist = 0;
+  __syncthreads();
+  const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
+  for (i64 beg = cb; beg < ce; beg += P2TS) {
+    p2_insert_tile(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0xFFFFFFFFu, out);
+    p2_flush(S, out);
+  }
+  p2_flush_final(S, out);
+}
+
+// level 2: workgroup b splits level-1 bin b (keys[bin_base[b] .. bin_base[b+1]), padding included) by the
+// next bits2 bits.  Its output region starts at bin_base[b] + b * P2SLACK (room for the rounding of its
+// 512 windows); window starts go to win_off; the unused end of the region is marked "no entry".
+__global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, u32 *out, u64 *win_off) {
+  __shared__ Stage2 S;
+  const i64 sb = (i64)bin_base[blockIdx.x], se = (i64)bin_base[blockIdx.x + 1];
+  const u32 mask = (1u << bits2) - 1u;
+  const u64 obase = (u64)sb + (u64)blockIdx.x * P2SLACK, onext = (u64)se + (u64)(blockIdx.x + 1) * P2SLACK;
+  for (int b = threadIdx.x; b < PBINS; b += P2T) S.cnt[b] = 0;
+  if (threadIdx.x == 0) S.nlist = 0;
+  __syncthreads();
+  for (i64 k0 = sb; k0 < se; k0 += 8 * P2T) {
+    u32 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.cnt[(v[j] >> WBITS) & mask], 1u);
+  }
+  __syncthreads();
+  u32 tot;
+  const u32 hb = (S.cnt[threadIdx.x] + (P2U - 1)) / P2U * P2U;   // P2T == PBINS: one sub-bin per thread
+  const u32 pre = p2_scan(hb, S.scratch, tot);
+  S.cur[threadIdx.x] = obase + pre;
+  S.cnt[threadIdx.x] = 0;
+  if (threadIdx.x <= mask) win_off[((i64)blockIdx.x << bits2) + threadIdx.x] = obase + pre;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) win_off[(i64)gridDim.x << bits2] = onext;
+  for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
+  __syncthreads();
+  for (i64 beg = sb; beg < se; beg += P2TS) {
+    p2_insert_tile(S, keys, beg, std::min<i64>(beg + P2TS, se), WBITS, mask, out);
+    p2_flush(S, out);
+  }
+  p2_flush_final(S, out);
+}
+
 __global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 nwin, u64 *cnt) {
   i64 w = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (w >= nwin) return;
@@ -223,6 +404,7 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
 }
 
 int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) {
+  static_assert(P2T == PBINS, "p2_level2_kernel maps one sub-bin to one thread");
   EventTimer tm;
   tm.start();
   const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18 for m < 2^32
@@ -233,27 +415,28 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, PT)));
+  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, P2TS)));
+  const i64 chunk = cdiv(cdiv(nlog, G), P2TS) * P2TS;
   DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot, ovf;
   int rc;
   if ((rc = ovf.alloc(4))) return rc;
   PSG_HIP(hipMemsetAsync(ovf.p, 0, 4, stream()));
   const i64 nwin_slots = bits2 ? ((i64)PBINS << bits2) : PBINS;
-  if ((rc = part1.alloc(nlog * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
+  const i64 cap1 = nlog + P2SLACK * G + 64;                 // level-1 output incl. the rounding of every (workgroup, bin) segment
+  if ((rc = part1.alloc(cap1 * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
       (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
     return rc;
-  hipLaunchKernelGGL(part_count_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, counts.as<u32>());
-  hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
-  hipLaunchKernelGGL(part_scatter_kernel, dim3(G), dim3(PNT), 0, stream(), d_log, nlog, shift1, off.as<u64>(), part1.as<u32>());
+  hipLaunchKernelGGL(p2_count_kernel, dim3(G), dim3(P2T), 0, stream(), d_log, nlog, chunk, shift1, counts.as<u32>());
+  hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
+  hipLaunchKernelGGL(p2_scatter_kernel, dim3(G), dim3(P2T), 0, stream(), d_log, nlog, chunk, shift1, off.as<u64>(), part1.as<u32>());
   PSG_HIP(hipGetLastError());
   const u32 *sorted = part1.as<u32>();
   const u64 *woff = bin_base.as<u64>();
   if (bits2) {
-    // the log buffer itself is free now: reuse it as the level-2 output
-    hipLaunchKernelGGL(part_level2_kernel, dim3(PBINS), dim3(PNT), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, d_log, win_off.as<u64>());
-    PSG_HIP(hipMemcpyAsync(win_off.as<u64>() + nwin_slots, bin_base.as<u64>() + PBINS, 8, hipMemcpyDeviceToDevice, stream()));
+    if ((rc = part2.alloc((cap1 + P2SLACK * (PBINS + 1)) * 4))) return rc;
+    hipLaunchKernelGGL(p2_level2_kernel, dim3(PBINS), dim3(P2T), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, part2.as<u32>(), win_off.as<u64>());
     PSG_HIP(hipGetLastError());
-    sorted = d_log;
+    sorted = part2.as<u32>();
     woff = win_off.as<u64>();
   }
   hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, stream(), woff, nwin, cnt.as<u64>());
