@@ -36,12 +36,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # HBM bytes per streamed suffix of the stream kernel, from the PMC passes committed in
 # profiles/r01_pmc_summary.csv: (FETCH_SIZE + WRITE_SIZE) * 1024 / 2^31, keyed by rank layout
 # (bytes of rank structure per BWT symbol):
-#   16.0 = symbol-major layout, rank-log mode: (1.468e8 + 1.049e7) KB -> 75.0 B/suffix
-#   17.0 = interleaved blocks B=64 with atomics (first version):          170.6 B/suffix
+#   16.0 = symbol-major layout, rank-log mode: (1.407e8 + 9.06e6) KB -> 71.4 B/suffix
+#          (64 rank sector + 4 log + ~1 text + gt words; 75.0 before the 64-byte text blocks / 16-byte gt_out
+#          stores; the first version -- interleaved blocks B=64 with atomics -- moved 170.6 B/suffix)
 # Calibration (profiles/r01_membench.txt + same csv): FETCH_SIZE*1024 is exact for random
 # 16-byte loads (64 B per request) and reads 1/2 for wide coalesced streams on gfx950; this
 # kernel's traffic is random-sector traffic, so no correction is applied.
-PMC_TRAFFIC_B_PER_SUFFIX = {16.0: 75.0, 17.0: 170.6}
+PMC_TRAFFIC_B_PER_SUFFIX = {16.0: 71.4}
 
 
 def parse():
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--max-chains", type=int, default=0)
     ap.add_argument("--rank-block", type=int, default=0, help="data bytes per rank block (0=auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
 
@@ -320,7 +321,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (PMC_TRAFFIC_B_PER_SUFFIX.get(round(rk_bytes / ls, 1)) or 0) * stream_suffixes or None,
                          "traffic_source": "PMC FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_summary.csv (bytes per launch)",
-                         "random_access_ceiling": "profiles/r01_membench.txt: dependent random 16-byte loads (one 64 B sector each) top out at 51 G/s on this chip = 3.3 TB/s of sectors; one sector per suffix is this kernel's floor",
+                         "random_access_ceiling": "profiles/r01_membench.txt: dependent random 16-byte loads (one 64 B sector each) top out at 48-51 G/s on this chip (46.7 G/s with this kernel's log stores and text loads mixed in); one sector per suffix is this kernel's floor, i.e. >= 42 ms per 2^31 suffixes",
                          "algorithmic_bytes_per_suffix": A_STREAM, "suffixes_per_launch": stream_suffixes,
                          "avg_launch_ms": 1e3 * kernel_s},
             "merge_roofline": {"achieved": A_MERGE * (oe - ob) / per["merge"] / 1e9, "unit": "GB/s", "note": "includes plan build (rank samples over the merge bitvector)"},

@@ -199,12 +199,15 @@ __device__ __forceinline__ u32 p2_scan(u32 v, u32 *scratch, u32 &total) {   // e
   return base + inc - v;
 }
 
+// EPT entries per thread: a tile should bring ~4 entries per bin in use, so that the 16 slots of headroom
+// above the flush threshold are practically never exceeded
+template <int EPT>
 __device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 *keys, i64 beg, i64 end, int shift, u32 mask, u32 *out) {
-  u32 v[P2TS / P2T];
+  u32 v[EPT];
 #pragma unroll
-  for (int j = 0; j < P2TS / P2T; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
+  for (int j = 0; j < EPT; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
 #pragma unroll
-  for (int j = 0; j < P2TS / P2T; ++j) {
+  for (int j = 0; j < EPT; ++j) {
     if (v[j] == PAD) continue;
     const u32 b = (v[j] >> shift) & mask;
     const u32 slot = atomicAdd(&S.cnt[b], 1u);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(P2T) void p2_scatter_kernel(const u32 *keys, i64 n,
   __syncthreads();
   const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
   for (i64 beg = cb; beg < ce; beg += P2TS) {
-    p2_insert_tile(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0xFFFFFFFFu, out);
+    p2_insert_tile<P2TS / P2T>(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0xFFFFFFFFu, out);
     p2_flush(S, out);
   }
   p2_flush_final(S, out);
@@ -336,9 +339,12 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) win_off[(i64)gridDim.x << bits2] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  for (i64 beg = sb; beg < se; beg += P2TS) {
-    p2_insert_tile(S, keys, beg, std::min<i64>(beg + P2TS, se), WBITS, mask, out);
-    p2_flush(S, out);
+  if (bits2 >= 9) {
+    for (i64 beg = sb; beg < se; beg += 4 * P2T) { p2_insert_tile<4>(S, keys, beg, std::min<i64>(beg + 4 * P2T, se), WBITS, mask, out); p2_flush(S, out); }
+  } else if (bits2 == 8) {
+    for (i64 beg = sb; beg < se; beg += 2 * P2T) { p2_insert_tile<2>(S, keys, beg, std::min<i64>(beg + 2 * P2T, se), WBITS, mask, out); p2_flush(S, out); }
+  } else {
+    for (i64 beg = sb; beg < se; beg += P2T) { p2_insert_tile<1>(S, keys, beg, std::min<i64>(beg + P2T, se), WBITS, mask, out); p2_flush(S, out); }
   }
   p2_flush_final(S, out);
 }
