@@ -199,17 +199,24 @@ __device__ __forceinline__ u32 p2_scan(u32 v, u32 *scratch, u32 &total) {   // e
   return base + inc - v;
 }
 
+// bin of a value: (v >> shift) - base, the last bin (511) also takes everything above it -- the value
+// range need not be a power of two, so the top bin of level 1 may own a few windows more than the others
+__device__ __forceinline__ u32 p2_bin(u32 v, int shift, u32 base) {
+  const u32 b = (v >> shift) - base;
+  return b < PBINS - 1 ? b : PBINS - 1;
+}
+
 // EPT entries per thread: a tile should bring ~4 entries per bin in use, so that the 16 slots of headroom
 // above the flush threshold are practically never exceeded
 template <int EPT>
-__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 *keys, i64 beg, i64 end, int shift, u32 mask, u32 *out) {
+__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 *keys, i64 beg, i64 end, int shift, u32 base, u32 *out) {
   u32 v[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     if (v[j] == PAD) continue;
-    const u32 b = (v[j] >> shift) & mask;
+    const u32 b = p2_bin(v[j], shift, base);
     const u32 slot = atomicAdd(&S.cnt[b], 1u);
     if (slot < P2C) S.buf[b][slot] = v[j];
     else out[atomicAdd((unsigned long long *)&S.cur[b], 1ull)] = v[j];   // bin full between two flushes: rare, written directly
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(P2T) void p2_count_kernel(const u32 *keys, i64 n, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < ce ? keys[k] : PAD; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] >> shift], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[p2_bin(v[j], shift, 0)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < PBINS; b += P2T) counts[(i64)blockIdx.x * PBINS + b] = h[b];
@@ -305,19 +312,21 @@ __global__ __launch_bounds__(P2T) void p2_scatter_kernel(const u32 *keys, i64 n,
   __syncthreads();
   const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
   for (i64 beg = cb; beg < ce; beg += P2TS) {
-    p2_insert_tile<P2TS / P2T>(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0xFFFFFFFFu, out);
+    p2_insert_tile<P2TS / P2T>(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0u, out);
     p2_flush(S, out);
   }
   p2_flush_final(S, out);
 }
 
-// level 2: workgroup b splits level-1 bin b (keys[bin_base[b] .. bin_base[b+1]), padding included) by the
-// next bits2 bits.  Its output region starts at bin_base[b] + b * P2SLACK (room for the rounding of its
-// 512 windows); window starts go to win_off; the unused end of the region is marked "no entry".
-__global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, u32 *out, u64 *win_off) {
+// level 2: workgroup b splits level-1 bin b (keys[bin_base[b] .. bin_base[b+1]), padding included) into its
+// windows (b << bits2) .. ; the top bin owns all windows up to nwin (at most 512).  Its output region starts
+// at bin_base[b] + b * P2SLACK (room for the rounding of its windows); window starts go to win_off; the
+// unused end of the region is marked "no entry".
+__global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u64 *bin_base, int bits2, i64 nwin, u32 *out, u64 *win_off) {
   __shared__ Stage2 S;
   const i64 sb = (i64)bin_base[blockIdx.x], se = (i64)bin_base[blockIdx.x + 1];
-  const u32 mask = (1u << bits2) - 1u;
+  const u32 base = (u32)blockIdx.x << bits2;
+  const i64 nsub = std::max<i64>(0, blockIdx.x == PBINS - 1 ? nwin - (i64)base : std::min<i64>((i64)1 << bits2, nwin - (i64)base));
   const u64 obase = (u64)sb + (u64)blockIdx.x * P2SLACK, onext = (u64)se + (u64)(blockIdx.x + 1) * P2SLACK;
   for (int b = threadIdx.x; b < PBINS; b += P2T) S.cnt[b] = 0;
   if (threadIdx.x == 0) S.nlist = 0;
@@ -327,24 +336,24 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
 #pragma unroll
     for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.cnt[(v[j] >> WBITS) & mask], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.cnt[p2_bin(v[j], WBITS, base)], 1u);
   }
   __syncthreads();
   u32 tot;
-  const u32 hb = (S.cnt[threadIdx.x] + (P2U - 1)) / P2U * P2U;   // P2T == PBINS: one sub-bin per thread
+  const u32 hb = (S.cnt[threadIdx.x] + (P2U - 1)) / P2U * P2U;   // P2T == PBINS: one window per thread
   const u32 pre = p2_scan(hb, S.scratch, tot);
   S.cur[threadIdx.x] = obase + pre;
   S.cnt[threadIdx.x] = 0;
-  if (threadIdx.x <= mask) win_off[((i64)blockIdx.x << bits2) + threadIdx.x] = obase + pre;
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) win_off[(i64)gridDim.x << bits2] = onext;
+  if ((i64)threadIdx.x < nsub) win_off[(i64)base + threadIdx.x] = obase + pre;
+  if (blockIdx.x == PBINS - 1 && threadIdx.x == 0) win_off[nwin] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  if (bits2 >= 9) {
-    for (i64 beg = sb; beg < se; beg += 4 * P2T) { p2_insert_tile<4>(S, keys, beg, std::min<i64>(beg + 4 * P2T, se), WBITS, mask, out); p2_flush(S, out); }
-  } else if (bits2 == 8) {
-    for (i64 beg = sb; beg < se; beg += 2 * P2T) { p2_insert_tile<2>(S, keys, beg, std::min<i64>(beg + 2 * P2T, se), WBITS, mask, out); p2_flush(S, out); }
+  if (nsub > 256) {
+    for (i64 beg = sb; beg < se; beg += 4 * P2T) { p2_insert_tile<4>(S, keys, beg, std::min<i64>(beg + 4 * P2T, se), WBITS, base, out); p2_flush(S, out); }
+  } else if (nsub > 128) {
+    for (i64 beg = sb; beg < se; beg += 2 * P2T) { p2_insert_tile<2>(S, keys, beg, std::min<i64>(beg + 2 * P2T, se), WBITS, base, out); p2_flush(S, out); }
   } else {
-    for (i64 beg = sb; beg < se; beg += P2T) { p2_insert_tile<1>(S, keys, beg, std::min<i64>(beg + P2T, se), WBITS, mask, out); p2_flush(S, out); }
+    for (i64 beg = sb; beg < se; beg += P2T) { p2_insert_tile<1>(S, keys, beg, std::min<i64>(beg + P2T, se), WBITS, base, out); p2_flush(S, out); }
   }
   p2_flush_final(S, out);
 }
@@ -414,9 +423,10 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   EventTimer tm;
   tm.start();
   const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18 for m < 2^32
-  int bits_total = 0;
-  while (((i64)1 << bits_total) < nwin) ++bits_total;
-  const int bits2 = bits_total > 9 ? bits_total - 9 : 0;   // level 2 only when there are > 512 windows
+  // level 2 only when there are > 512 windows: 511 level-1 bins of 2^bits2 windows + a top bin that takes the
+  // rest (<= 512 windows).  m + 1 = 2^31 + 1 (a 2 GiB half-block) thus uses all 512 bins, not 257 of them.
+  int bits2 = 0;
+  if (nwin > PBINS) { bits2 = 1; while (nwin - (i64)(PBINS - 1) * ((i64)1 << bits2) > PBINS) ++bits2; }
   const int shift1 = WBITS + bits2;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -427,7 +437,7 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   int rc;
   if ((rc = ovf.alloc(4))) return rc;
   PSG_HIP(hipMemsetAsync(ovf.p, 0, 4, stream()));
-  const i64 nwin_slots = bits2 ? ((i64)PBINS << bits2) : PBINS;
+  const i64 nwin_slots = (bits2 ? ((i64)PBINS << bits2) : PBINS) + PBINS + 2;
   const i64 cap1 = nlog + P2SLACK * G + 64;                 // level-1 output incl. the rounding of every (workgroup, bin) segment
   if ((rc = part1.alloc(cap1 * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
       (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
@@ -440,7 +450,7 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   const u64 *woff = bin_base.as<u64>();
   if (bits2) {
     if ((rc = part2.alloc((cap1 + P2SLACK * (PBINS + 1)) * 4))) return rc;
-    hipLaunchKernelGGL(p2_level2_kernel, dim3(PBINS), dim3(P2T), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, part2.as<u32>(), win_off.as<u64>());
+    hipLaunchKernelGGL(p2_level2_kernel, dim3(PBINS), dim3(P2T), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, nwin, part2.as<u32>(), win_off.as<u64>());
     PSG_HIP(hipGetLastError());
     sorted = part2.as<u32>();
     woff = win_off.as<u64>();
