@@ -209,10 +209,12 @@ __device__ __forceinline__ u32 p2_bin(u32 v, int shift, u32 base) {
 // EPT entries per thread: a tile should bring ~4 entries per bin in use, so that the 16 slots of headroom
 // above the flush threshold are practically never exceeded
 template <int EPT>
-__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 *keys, i64 beg, i64 end, int shift, u32 base, u32 *out) {
-  u32 v[EPT];
+__device__ __forceinline__ void p2_load_tile(u32 (&v)[EPT], const u32 *keys, i64 beg, i64 end) {
 #pragma unroll
   for (int j = 0; j < EPT; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
+}
+template <int EPT>
+__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 (&v)[EPT], int shift, u32 base, u32 *out) {
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     if (v[j] == PAD) continue;
@@ -268,6 +270,21 @@ __device__ __forceinline__ void p2_flush_final(Stage2 &S, u32 *out) {
   }
 }
 
+// all tiles of keys[beg0, end0): the loads of the next tile are in flight while this one is inserted and flushed
+template <int EPT>
+__device__ __forceinline__ void p2_run(Stage2 &S, const u32 *keys, i64 beg0, i64 end0, int shift, u32 base, u32 *out) {
+  u32 v[EPT], vn[EPT];
+  p2_load_tile<EPT>(v, keys, beg0, end0);
+  for (i64 beg = beg0; beg < end0; beg += EPT * P2T) {
+    p2_load_tile<EPT>(vn, keys, beg + EPT * P2T, end0);
+    p2_insert_tile<EPT>(S, v, shift, base, out);
+    p2_flush(S, out);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = vn[j];
+  }
+  p2_flush_final(S, out);
+}
+
 // level 1, step A: workgroup g counts the entries of its chunk [g*chunk, (g+1)*chunk)
 __global__ __launch_bounds__(P2T) void p2_count_kernel(const u32 *keys, i64 n, i64 chunk, int shift, u32 *counts) {
   __shared__ u32 h[PBINS];
@@ -311,11 +328,7 @@ __global__ __launch_bounds__(P2T) void p2_scatter_kernel(const u32 *keys, i64 n,
   if (threadIdx.x == 0) S.nlist = 0;
   __syncthreads();
   const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
-  for (i64 beg = cb; beg < ce; beg += P2TS) {
-    p2_insert_tile<P2TS / P2T>(S, keys, beg, std::min<i64>(beg + P2TS, ce), shift, 0u, out);
-    p2_flush(S, out);
-  }
-  p2_flush_final(S, out);
+  p2_run<P2TS / P2T>(S, keys, cb, ce, shift, 0u, out);
 }
 
 // level 2: workgroup b splits level-1 bin b (keys[bin_base[b] .. bin_base[b+1]), padding included) into its
@@ -348,14 +361,9 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   if (blockIdx.x == PBINS - 1 && threadIdx.x == 0) win_off[nwin] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  if (nsub > 256) {
-    for (i64 beg = sb; beg < se; beg += 4 * P2T) { p2_insert_tile<4>(S, keys, beg, std::min<i64>(beg + 4 * P2T, se), WBITS, base, out); p2_flush(S, out); }
-  } else if (nsub > 128) {
-    for (i64 beg = sb; beg < se; beg += 2 * P2T) { p2_insert_tile<2>(S, keys, beg, std::min<i64>(beg + 2 * P2T, se), WBITS, base, out); p2_flush(S, out); }
-  } else {
-    for (i64 beg = sb; beg < se; beg += P2T) { p2_insert_tile<1>(S, keys, beg, std::min<i64>(beg + P2T, se), WBITS, base, out); p2_flush(S, out); }
-  }
-  p2_flush_final(S, out);
+  if (nsub > 256) p2_run<4>(S, keys, sb, se, WBITS, base, out);
+  else if (nsub > 128) p2_run<2>(S, keys, sb, se, WBITS, base, out);
+  else p2_run<1>(S, keys, sb, se, WBITS, base, out);
 }
 
 __global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 nwin, u64 *cnt) {
