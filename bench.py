@@ -166,8 +166,12 @@ def main():
     from psascan_amd import api, extras
     L = psascan_amd.lib(local)
     if world > 1:
-        # everything on torch's current stream so RCCL collectives and our kernels are ordered
-        L.psg_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        # everything on ONE explicit stream so RCCL collectives and our kernels are ordered.  (torch's default
+        # stream has handle 0, which psg_set_stream takes as "create your own": make a real stream current.)
+        shared_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(shared_stream)
+        assert shared_stream.cuda_stream != 0
+        L.psg_set_stream(C.c_void_p(shared_stream.cuda_stream))
 
     def log(*a):
         if rank == 0:
@@ -195,7 +199,7 @@ def main():
     gt_words = max(cuts[r + 1] - cuts[r] for r in range(world)) // 32 + 4
     gap_words = ls + 2
     if world > 1:
-        a2a_ops = D.HipA2AOps(torch, api, "cuda", full_sync=os.environ.get("PSASCAN_DIST_BACKEND", "nccl") != "nccl")
+        a2a_ops = D.HipA2AOps(torch, api, "cuda", full_sync=True)   # device-wide sync around every collective: cheap next to the collectives, and independent of stream identity
         gt_mine = torch.zeros(gt_words, dtype=torch.int32, device="cuda")
     else:
         gap_buf = api.zeros(4 * gap_words)
