@@ -222,9 +222,10 @@ def main():
         t1 = time.perf_counter()
         start_rank = 0 if te + ctx == n else -1   # exact only at n (rank of the empty suffix = 0)
         if world == 1:
-            L.psg_memset(C.c_void_p(gap_ptr), 0, 4 * gap_words)
+            # like the reference, the pass starts from a fresh gap array (partial_sufsort.hpp:405): no memset here,
+            # the library zero-fills or overwrites it (PSG_GAP_UNINITIALIZED)
             fin, st = api.stream_gap(rk, Lh["i0"], last_left, d_text.at(tb), te - tb, gt_in, start_rank, gap_ptr, gt_out,
-                                     args.max_chains, right_context=ctx)
+                                     args.max_chains, right_context=ctx, fresh_gap=True)
             t2 = t3 = time.perf_counter()
             if os.environ.get("PSG_TIMING"):
                 ta = time.perf_counter(); api.sync(); tb_ = time.perf_counter(); api.sync(); tc = time.perf_counter()

@@ -197,12 +197,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     psg_rank_t *rankL = nullptr;
     CK(psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL));
     log_phase("Construct rank (left half, device)", t0, ls);
-    Dev gapA(4 * (ls + 2), true), gtA(4 * ((rs + 31) / 32 + 2), true);
+    Dev gapA(4 * (ls + 2), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
     int64_t initA = psa_host::rank_by_search(text.data(), n, L, e);
     psg_stream_stats st;
     t0 = wclock();
-    CK(psg_stream_gap(rankL, L.i0, text[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
-                      gtA.as<uint32_t>(), max_chains, nullptr, &st));
+    CK(psg_stream_gap_ex(rankL, L.i0, text[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, 0, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
+                         gtA.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankL);
@@ -233,10 +233,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     d_bbwt.release();
     log_phase("Construct rank (block, device)", t0, bs);
     const int64_t T = n - e;
-    Dev gapB(4 * (bs + 2), true);
+    Dev gapB(4 * (bs + 2), false);
     t0 = wclock();
-    CK(psg_stream_gap(rankB, block_i0, text[(size_t)e - 1], d_text.as<uint8_t>() + e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
-                      gt_new.as<uint32_t>(), max_chains, nullptr, &st));
+    CK(psg_stream_gap_ex(rankB, block_i0, text[(size_t)e - 1], d_text.as<uint8_t>() + e, T, 0, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
+                         gt_new.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankB);

@@ -107,6 +107,18 @@ int psg_stream_gap_ctx(const psg_rank_t *rank, int64_t block_i0, int block_last_
                        uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank,
                        psg_stream_stats *stats);
 
+/* The reference hands compute_gap a freshly constructed (zeroed) buffered_gap_array
+ * (partial_sufsort.hpp:405-407, 503-505).  Same pass as psg_stream_gap_ctx with
+ * flags & PSG_GAP_UNINITIALIZED: d_gap may hold anything on entry and holds exactly this pass's
+ * counts on return -- the library zero-fills or overwrites as suits the update mode (saves the
+ * caller's memset and the read half of the read-modify-write of every counter).              */
+#define PSG_GAP_UNINITIALIZED 1
+int psg_stream_gap_ex(const psg_rank_t *rank, int64_t block_i0, int block_last_symbol,
+                      const uint8_t *d_tail, int64_t tail_len, int64_t right_context,
+                      const uint32_t *d_gt_in, int64_t rank_at_context_end, uint32_t *d_gap,
+                      uint32_t *d_gt_out, int64_t max_chains, int flags, int64_t *h_final_rank,
+                      psg_stream_stats *stats);
+
 /* ---- buffered_gap_array::convert_to_bitvector, partial_sufsort.hpp:441
  *      (gap_array.hpp:273-364): for j=0..m: gap[j] ones, then a zero (none after j=m).
  *      d_bv needs room for m + sum(gap) bits rounded up to 32; *nbits = m + sum(gap). ---- */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "psg_rank_free": (None, [_vp]),
     "psg_stream_gap": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_stream_gap_ctx": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_stream_gap_ex": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_stream_gap_log": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC),
                                   C.POINTER(_vp), C.POINTER(_i64)]),
     "psg_log_partition": (_int, [_vp, _i64, _i64, _int, _vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -119,14 +119,21 @@ class StreamStats:
 
 
 def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_tail_end, d_gap, d_gt_out,
-               max_chains=0, right_context=0):
+               max_chains=0, right_context=0, fresh_gap=False):
     """One streaming pass (compute_gap<T>), optionally over a sub-range of the tail with
-    `right_context` bytes/bits of valid text/gt to its right.  Returns (final_rank, StreamStats)."""
+    `right_context` bytes/bits of valid text/gt to its right.  fresh_gap: d_gap is uninitialised
+    (the reference's freshly constructed gap array) -- the pass zero-fills / overwrites it.
+    Returns (final_rank, StreamStats)."""
     fin = C.c_int64(0)
     st = StreamStatsC()
-    check(lib().psg_stream_gap_ctx(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context,
-                                   _ptr(d_gt_in), rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains,
-                                   C.byref(fin), C.byref(st)))
+    if fresh_gap:
+        check(lib().psg_stream_gap_ex(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context,
+                                      _ptr(d_gt_in), rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains, 1,
+                                      C.byref(fin), C.byref(st)))
+    else:
+        check(lib().psg_stream_gap_ctx(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context,
+                                       _ptr(d_gt_in), rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains,
+                                       C.byref(fin), C.byref(st)))
     return fin.value, StreamStats(st)
 
 

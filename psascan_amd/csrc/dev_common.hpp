@@ -92,7 +92,8 @@ static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
 // gap[v] += #{entries of log equal to v} for v in [0, m]; entries 0xFFFFFFFF are skipped.
 // Sorts the log by its high bits (in place semantics: log is clobbered) and histograms
 // LDS-sized windows -- replaces one random atomic per streamed suffix (gap_hist.hip).
-int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms);
+// overwrite: d_gap holds garbage on entry and exactly the histogram on return (no zero-fill needed)
+int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
 
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);

@@ -366,15 +366,28 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   else p2_run<1>(S, keys, sb, se, WBITS, base, out);
 }
 
-__global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 nwin, u64 *cnt) {
+// work items per window; all_windows: at least one each (the overwriting histogram must visit empty windows too)
+__global__ __launch_bounds__(PSG_WG) void item_count_kernel(const u64 *off, i64 nwin, u64 *cnt, int all_windows) {
   i64 w = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (w >= nwin) return;
   u64 c = off[w + 1] - off[w];
-  cnt[w] = (c + CAP - 1) / CAP;
+  u64 k = (c + CAP - 1) / CAP;
+  cnt[w] = (all_windows && k == 0) ? 1 : k;
+}
+
+// overwriting histogram: a window with several work items is accumulated with atomics, so it starts from zero
+__global__ __launch_bounds__(PSG_WG) void zero_multi_item_windows_kernel(const u64 *off, i64 nwin, i64 m, u32 *gap) {
+  const i64 w = blockIdx.x;
+  if ((i64)(off[w + 1] - off[w]) <= CAP) return;
+  for (i64 k = (w << WBITS) + threadIdx.x; k < ((w + 1) << WBITS) && k <= m; k += PSG_WG) gap[k] = 0;
 }
 
 // one work item = up to CAP log entries of one window: LDS histogram, coalesced add to the gap array
-__global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap, int *ovf) {
+// OVERWRITE: the gap array holds garbage on entry; single-item windows are stored, not added
+// 512 threads: the 64 KiB histogram allows two workgroups per CU, and the kernel needs loads in flight
+#define HWG 512
+template <bool OVERWRITE>
+__global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap, int *ovf) {
   __shared__ __attribute__((aligned(16))) u32 h[WSIZE];
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
@@ -386,26 +399,27 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
     }
     s_w = lo;
   }
-  for (int k = threadIdx.x; k < WSIZE / 4; k += PSG_WG) ((uint4 *)h)[k] = make_uint4(0, 0, 0, 0);
+  for (int k = threadIdx.x; k < WSIZE / 4; k += HWG) ((uint4 *)h)[k] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   i64 w = s_w;
   i64 sub = item - (i64)item_pref[w];
   i64 beg = (i64)off[w] + sub * CAP, end = std::min<i64>(beg + CAP, (i64)off[w + 1]);
   bool single = (i64)(off[w + 1] - off[w]) <= CAP;
-  for (i64 k0 = beg; k0 < end; k0 += 4 * PSG_WG) {   // 4 independent loads in flight per thread
-    u32 v[4];
+  for (i64 k0 = beg; k0 < end; k0 += 8 * HWG) {   // 8 independent loads in flight per thread
+    u32 v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { i64 k = k0 + j * PSG_WG + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
+    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * HWG + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] & (WSIZE - 1)], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] & (WSIZE - 1)], 1u);
   }
   __syncthreads();
   i64 base = w << WBITS;
   bool vec = single && base + WSIZE - 1 <= m && ((uintptr_t)(gap + base) & 15) == 0;
   if (vec) {   // whole window inside the array: coalesced 16-byte read-modify-writes
-    for (int k = threadIdx.x; k < WSIZE / 4; k += PSG_WG) {
+    for (int k = threadIdx.x; k < WSIZE / 4; k += HWG) {
       uint4 c = ((const uint4 *)h)[k];
-      if (c.x | c.y | c.z | c.w) {
+      if (OVERWRITE) ((uint4 *)(gap + base))[k] = c;
+      else if (c.x | c.y | c.z | c.w) {
         uint4 *gp = (uint4 *)(gap + base) + k;
         uint4 g = *gp;
         uint4 o = g;
@@ -415,10 +429,11 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
       }
     }
   } else {
-    for (int k = threadIdx.x; k < WSIZE; k += PSG_WG) {
+    for (int k = threadIdx.x; k < WSIZE; k += HWG) {
       u32 c = h[k];
       i64 idx = base + k;
-      if (c && idx <= m) {
+      if (OVERWRITE && single) { if (idx <= m) gap[idx] = c; }
+      else if (c && idx <= m) {
         if (single) { u32 o = gap[idx]; gap[idx] = o + c; if (o + c < o) *ovf = 1; }
         else if (atomicAdd(&gap[idx], c) + c < c) *ovf = 1;
       }
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(PSG_WG) void hist_items_kernel(const u32 *keys, con
   }
 }
 
-int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) {
+int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
   static_assert(P2T == PBINS, "p2_level2_kernel maps one sub-bin to one thread");
   EventTimer tm;
   tm.start();
@@ -463,7 +478,8 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
     sorted = part2.as<u32>();
     woff = win_off.as<u64>();
   }
-  hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, stream(), woff, nwin, cnt.as<u64>());
+  hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, stream(), woff, nwin, cnt.as<u64>(), overwrite ? 1 : 0);
+  if (overwrite) hipLaunchKernelGGL(zero_multi_item_windows_kernel, dim3((unsigned)nwin), dim3(PSG_WG), 0, stream(), woff, nwin, m, d_gap);
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(cnt.as<u64>(), nwin, tot.as<u64>()))) return rc;
   u64 items = 0;
@@ -471,7 +487,8 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms) 
   PSG_HIP(psg::sync_stream());
   memcpy(&items, pinned_buf(3, 64), 8);
   if (items > 0) {
-    hipLaunchKernelGGL(hist_items_kernel, dim3((unsigned)items), dim3(PSG_WG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
+    if (overwrite) hipLaunchKernelGGL(hist_items_kernel<true>, dim3((unsigned)items), dim3(HWG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
+    else hipLaunchKernelGGL(hist_items_kernel<false>, dim3((unsigned)items), dim3(HWG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
     PSG_HIP(hipGetLastError());
   }
   tm.stop();
@@ -543,12 +560,12 @@ extern "C" int psg_gap_hist(uint32_t *d_log, int64_t nlog, int64_t value_base, i
   PSG_REQUIRE(d_log, "psg_gap_hist: log required");
   hipLaunchKernelGGL(sub_base_kernel, dim3((unsigned)cdiv(nlog, PSG_WG)), dim3(PSG_WG), 0, stream(), d_log, nlog, (u32)value_base, (u32)count);
   PSG_HIP(hipGetLastError());
-  return psg::gap_hist_from_log(d_log, nlog, count - 1, d_gap_slice, nullptr);
+  return psg::gap_hist_from_log(d_log, nlog, count - 1, d_gap_slice, nullptr, false);
 }
 
 // test entry (include/psascan_amd_extras.h): histogram an explicit rank log
 extern "C" int psgx_gap_hist(uint32_t *d_log, int64_t nlog, int64_t m, uint32_t *d_gap) {
   PSG_REQUIRE(d_log && d_gap && nlog >= 0 && m >= 0 && m < 0xFFFFFFFFll, "psgx_gap_hist");
   if (nlog == 0) return 0;
-  return psg::gap_hist_from_log(d_log, nlog, m, d_gap, nullptr);
+  return psg::gap_hist_from_log(d_log, nlog, m, d_gap, nullptr, false);
 }

@@ -892,13 +892,22 @@ extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, con
 
 static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out);
+                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh);
 
 extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                                   int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
                                   uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
   PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
-  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr);
+  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr, false);
+}
+// the gap array is uninitialised on entry (PSG_GAP_UNINITIALIZED): zero-filled or overwritten by the pass
+extern "C" int psg_stream_gap_ex(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
+                                 int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
+                                 uint32_t *d_gt_out, int64_t max_chains, int flags, int64_t *h_final_rank, psg_stream_stats *stats) {
+  PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
+  PSG_REQUIRE((flags & ~PSG_GAP_UNINITIALIZED) == 0, "psg_stream_gap_ex: unknown flag");
+  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr,
+                     (flags & PSG_GAP_UNINITIALIZED) != 0);
 }
 
 // same pass, but the ranks are handed back as a log (one u32 per streamed suffix, 0xFFFFFFFF =
@@ -911,23 +920,23 @@ extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym,
   PSG_REQUIRE(d_log && nlog, "psg_stream_gap_log: output pointers required");
   PSG_REQUIRE(r && r->m < 0xFFFFFFFFll, "psg_stream_gap_log: block too large for a 32-bit rank log");
   *d_log = nullptr; *nlog = 0;
-  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, h_final_rank, stats, d_log, nlog);
+  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, h_final_rank, stats, d_log, nlog, false);
 }
 
 static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
                         const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out);
+                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh);
 
 // A pass over a long tail is cut into chunks of at most 2^31 suffixes, streamed right to left with
 // the exact hand-over rank: bounds the rank log (8 + 8 GiB) and keeps every chunk in rank-log mode.
 #define PSG_PASS_CHUNK ((int64_t)1 << 31)
 static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out) {
+                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh) {
   int64_t chunk = PSG_PASS_CHUNK;
   if (const char *e = getenv("PSG_PASS_CHUNK")) { int64_t v = atoll(e); if (v >= 64) chunk = v / 64 * 64; }   // tests
   if (log_out || T <= chunk)
-    return stream_chunk(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, log_out, nlog_out);
+    return stream_chunk(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, log_out, nlog_out, fresh);
   psg_stream_stats acc = {};
   int64_t fin = rank_at_end;
   for (int64_t u_lo = 0; u_lo < T; u_lo += chunk) {     // u = distance from the tail end
@@ -936,7 +945,7 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
     // first chunk: the caller's context / start rank; later chunks start exactly where the previous one ended
     int rc = stream_chunk(r, i0, last_sym, d_tail + (T - u_hi), u_hi - u_lo, u_lo == 0 ? ctx : 0,
                           d_gt_in ? d_gt_in + ((u_lo + (u_lo == 0 ? 0 : ctx)) >> 5) : nullptr, u_lo == 0 ? rank_at_end : fin, d_gap,
-                          d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr, max_chains, &fin, &st, nullptr, nullptr);
+                          d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr, max_chains, &fin, &st, nullptr, nullptr, fresh && u_lo == 0);
     if (rc) return rc;
     acc.n_chains = std::max(acc.n_chains, st.n_chains); acc.chain_len = st.chain_len;
     acc.warmup_steps = std::max(acc.warmup_steps, st.warmup_steps);
@@ -951,14 +960,17 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
 
 static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
                         const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out) {
+                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh) {
   PSG_REQUIRE(ctx >= 0 && (ctx & 63) == 0, "psg_stream_gap_ctx: right context must be a multiple of 64");
   PSG_REQUIRE(r && (d_gap || log_out), "psg_stream_gap: rank and gap required");
   PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");
   PSG_REQUIRE((rank_at_end >= 0 && rank_at_end <= r->m) || (rank_at_end == -1 && ctx > 0),
               "psg_stream_gap: rank_at_tail_end out of range (-1 = unknown is only allowed with a right context)");
   psg_stream_stats st = {};
-  if (T == 0) { if (h_final_rank) *h_final_rank = rank_at_end; if (stats) *stats = st; return 0; }
+  if (T == 0) {
+    if (fresh && d_gap) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));
+    if (h_final_rank) *h_final_rank = rank_at_end; if (stats) *stats = st; return 0;
+  }
   PSG_REQUIRE(d_tail, "psg_stream_gap: tail text required");
   EventTimer total_tm, ktm;
   total_tm.start();
@@ -977,6 +989,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     if (want_log && r->m < 0xFFFFFFFFll && mode == 0) mode = 2;
     if (log_out) mode = 2;   // the caller wants the log itself
   }
+  if (fresh && mode != 2) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));   // the atomics need zeroes; the histogram overwrites
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
   // pass time: every chain has the same length)
   const int cpl = chains_per_lane(r);
@@ -1077,7 +1090,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     *nlog_out = K * L;
     log_d.p = nullptr;
   } else if (mode == 2) {
-    if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms))) return rc;
+    if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh))) return rc;
     log_d.alloc(16);   // give the log back to the pool before returning
   }
   st.hist_ms = hist_ms;

@@ -166,10 +166,10 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         d_lbwt = dev(L, "bwt", 16)
         # ---- step 3: pass A, right half streamed through rank(left BWT) (:403-414)
         rankL = api.rank_build(d_lbwt, ls)
-        gapA = api.zeros(4 * (ls + 2))
+        gapA = api.DeviceBuffer(4 * (ls + 2))     # fresh gap array: the pass zero-fills / overwrites it
         gtA = api.zeros(4 * ((rs + 31) // 32 + 1))
         initA = rank_by_search(tb, b, host_psa(L), e)
-        _, stA = api.stream_gap(rankL, L["i0"], text[mid - 1], d_text.at(mid), rs, d_rgt, initA, gapA, gtA, max_chains)
+        _, stA = api.stream_gap(rankL, L["i0"], text[mid - 1], d_text.at(mid), rs, d_rgt, initA, gapA, gtA, max_chains, fresh_gap=True)
         rankL.free()
         if stats is not None:
             stats.append(("A", b, e, stA))
@@ -191,9 +191,9 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         # ---- step 5: pass B, the tail streamed through rank(block BWT) (:500-514)
         rankB = api.rank_build(d_bbwt, bs)
         d_bbwt.free()
-        gapB = api.zeros(4 * (bs + 2))
+        gapB = api.DeviceBuffer(4 * (bs + 2))
         T = n - e
-        _, stB = api.stream_gap(rankB, block_i0, text[e - 1], d_text.at(e), T, gt_cur, 0, gapB, gt_new, max_chains)
+        _, stB = api.stream_gap(rankB, block_i0, text[e - 1], d_text.at(e), T, gt_cur, 0, gapB, gt_new, max_chains, fresh_gap=True)
         rankB.free()
         if stats is not None:
             stats.append(("B", b, e, stB))

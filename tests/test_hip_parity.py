@@ -169,13 +169,14 @@ def test_stream_gap_chunked_pass(A, monkeypatch, mode):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
-@pytest.mark.parametrize("case", ["uniform", "skewed", "uniform-atomic", "uniform-cpl2"])
+@pytest.mark.parametrize("case", ["uniform", "skewed", "uniform-atomic", "uniform-cpl2", "uniform-fresh", "skewed-fresh", "atomic-fresh"])
 def test_stream_gap_large_block(A, monkeypatch, case):
     """a block with more than 512 histogram windows (m > 8 Mi) and a tail long enough for the automatic
     rank-log mode: two-level partition + window histograms at a size where both levels are real.
     "skewed": all tail ranks fall into a handful of windows.  Checked against the CPU oracle."""
     import psascan_amd.extras as X
-    if case == "uniform-atomic":
+    fresh = case.endswith("-fresh")        # PSG_GAP_UNINITIALIZED: garbage in the gap array on entry
+    if case in ("uniform-atomic", "atomic-fresh"):
         monkeypatch.setenv("PSG_GAP_MODE", "atomic")
     if case == "uniform-cpl2":
         monkeypatch.setenv("PSG_CPL", "2")
@@ -183,7 +184,7 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     n = mid + T
     rng = np.random.default_rng(5)
     t = rng.integers(3, 255, n, dtype=np.uint8)
-    if case == "skewed":
+    if case.startswith("skewed"):
         t[mid:] = rng.integers(1, 3, T, dtype=np.uint8)     # tail over {1,2}: ranks cluster at the low end of the block's order
     t[mid - 1] = 0     # gt_in is only read where a tail symbol equals the block's last symbol: never, here
     d_text = A.upload(t, pad_to=16)
@@ -192,12 +193,12 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     gt_in = np.zeros((T + 7) // 8 + 8, np.uint8)
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(lbwt), Lh["i0"], 0, t, mid, n, gt_in, 0)
     r = A.rank_build(Lh["bwt"], mid)
-    d_gap = A.upload(np.full(mid + 1, 2, np.uint32))
+    d_gap = A.upload(np.full(mid + 1, 0xDEADBEEF if fresh else 2, np.uint32))
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 4))
-    fin, st = A.stream_gap(r, Lh["i0"], 0, d_text.at(mid), T, A.upload(gt_in, pad_to=16), 0, d_gap, d_gtout, 0)
-    assert fin == want_fin and (st.hist_ms > 0) == (case != "uniform-atomic")
+    fin, st = A.stream_gap(r, Lh["i0"], 0, d_text.at(mid), T, A.upload(gt_in, pad_to=16), 0, d_gap, d_gtout, 0, fresh_gap=fresh)
+    assert fin == want_fin and (st.hist_ms > 0) == ("atomic" not in case)
     got = A.download(d_gap, np.uint32, mid + 1).astype(np.uint64)
-    assert np.array_equal(got, want_gap + 2)
+    assert np.array_equal(got, want_gap + (0 if fresh else 2))
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
