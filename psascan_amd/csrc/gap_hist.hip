@@ -171,8 +171,16 @@ __global__ __launch_bounds__(PNT) void part_level2_kernel(const u32 *keys, const
 // the per-workgroup segment of a bin is rounded up to a multiple of 16 entries and the holes hold
 // the "no entry" value, which every consumer of the log already skips.
 // ---------------------------------------------------------------------------------------
+#ifndef P2L2_A
+#define P2L2_A 128
+#define P2L2_B 64
+#define P2L2_EA 4
+#define P2L2_EB 2
+#endif
+#ifndef P2TS
+#define P2TS 2048          // entries per level-1 tile
+#endif
 #define P2T 512            // threads per workgroup (2 workgroups per CU)
-#define P2TS 2048          // entries per tile
 #define P2C 32             // staging slots per bin
 #define P2U 16             // unit = 16 entries = one 64-byte sector
 #define P2SLACK ((i64)P2U * PBINS)   // rounding growth bound of one partition call per (workgroup | segment)
@@ -361,8 +369,8 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   if (blockIdx.x == PBINS - 1 && threadIdx.x == 0) win_off[nwin] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  if (nsub > 256) p2_run<4>(S, keys, sb, se, WBITS, base, out);
-  else if (nsub > 128) p2_run<2>(S, keys, sb, se, WBITS, base, out);
+  if (nsub > P2L2_A) p2_run<P2L2_EA>(S, keys, sb, se, WBITS, base, out);
+  else if (nsub > P2L2_B) p2_run<P2L2_EB>(S, keys, sb, se, WBITS, base, out);
   else p2_run<1>(S, keys, sb, se, WBITS, base, out);
 }
 
