@@ -18,16 +18,41 @@
 #define SM_ABSENT 0u
 #define SM_LIST 1u
 #define SM_BITMAP 2u
+#define SM_LIST8 3u          // 8-byte entries: word0 = #c before the bucket, bytes 4..7 = positions (0xFF = unused);
+                             // more than 4 occurrences: word0 |= 2^31, word1 = index of a 256-bit bitmap in the pool
+#define SM_CAP8 4
 #define SM_MODE_SHIFT 62
 #define SM_OFF_MASK ((1ull << SM_MODE_SHIFT) - 1ull)
 #define SM_SEG 4096          // positions per build segment (= seg_hist_kernel<256,64> granularity)
 #define SM_CAP 11            // positions that fit into a LIST entry
 
 // rank inside a loaded entry: e = E_c[bucket], off = i mod bucket size, t2 = descriptor of the symbol
+__device__ __forceinline__ u32 sm_pool_rank(const u8 *pool, u32 idx, u32 off) {   // ones below bit `off` of pool bitmap idx
+  const uint4 *bp = (const uint4 *)(pool + (size_t)idx * 32);
+  uint4 a = bp[0], b = bp[1];
+  u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32 cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int rem = (int)off - 32 * k;
+    u32 mask = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    cnt += __popc(w[k] & mask);
+  }
+  return cnt;
+}
+
 __device__ __forceinline__ u32 sm_rank_entry(const uint4 &e, const u8 *pool, u64 t2, u32 off) {
-  if ((u32)(t2 >> SM_MODE_SHIFT) == SM_BITMAP) {
+  const u32 mode = (u32)(t2 >> SM_MODE_SHIFT);
+  if (mode == SM_BITMAP) {
     u64 bm = (u64)e.z | ((u64)e.w << 32);
     return e.x + (u32)__popcll(bm & ((1ull << off) - 1ull));
+  }
+  if (mode == SM_LIST8) {   // e.x = count (| 2^31), e.y = four positions or the pool index
+    if (e.x & 0x80000000u) return (e.x & 0x7FFFFFFFu) + sm_pool_rank(pool, e.y, off);
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cnt += ((e.y >> (8 * j)) & 255u) < off;   // unused slots hold 0xFF, never < off (off <= 255)
+    return e.x + cnt;
   }
   u32 n = e.y & 255u;
   if (n != 0xFFu) {   // unused slots hold 0xFF, which is never < off (off <= 255)
@@ -40,17 +65,7 @@ __device__ __forceinline__ u32 sm_rank_entry(const uint4 &e, const u8 *pool, u64
     for (int j = 0; j < 4; ++j) cnt += ((e.w >> (8 * j)) & 255u) < off;
     return e.x + cnt;
   }
-  const uint4 *bp = (const uint4 *)(pool + (size_t)e.z * 32);   // dense bucket: 256-bit bitmap in the pool
-  uint4 a = bp[0], b = bp[1];
-  u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  u32 cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int rem = (int)off - 32 * k;
-    u32 mask = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-    cnt += __popc(w[k] & mask);
-  }
-  return e.x + cnt;
+  return e.x + sm_pool_rank(pool, e.z, off);   // dense bucket: 256-bit bitmap in the pool
 }
 
 // bit k of the result = (byte k of the 4-byte word == c)
@@ -70,12 +85,58 @@ struct SmListLds {                               // LIST phase (SM_NB buckets of
   // slot (bucket j, symbol c): {count, 12 position bytes}; rewritten IN PLACE into the finished entry
   uint4 slot[SM_NB * SM_OUT_STRIDE];
 };
+struct SmList8Lds {                              // LIST8 phase: all 16 buckets of the segment at once, 8-byte slots (~33 KiB)
+  uint2 slot[16 * SM_OUT_STRIDE];                // {count, 4 position bytes} -> the finished entry, in place
+};
 struct SmBitmapLds {                             // BITMAP phase (64 sub-buckets of 64)
   u64 bm[SM_MAX_BITMAP * 64];
   u32 cum[SM_MAX_BITMAP * 64];
 };
-union SmPhaseLds { SmListLds L; SmBitmapLds B; };
+union SmPhaseLds { SmListLds L; SmList8Lds L8; SmBitmapLds B; };
 
+// Dense buckets (more occurrences than an entry holds inline) of one phase of one workgroup: collected in a
+// list, ONE global atomic reserves their pool slots (a global atomic per bucket serialises on the cursor:
+// 8 M of them took 65 ms), then 8 lanes per bucket build the 256-bit bitmap.
+#define SM_DENSE_CAP 1024
+struct SmDense {
+  u32 n;          // dense buckets of this phase
+  u32 base;       // first pool slot of this phase
+  u16 item[SM_DENSE_CAP];   // (bucket within the segment) << 8 | symbol
+};
+// workgroup-wide; call between the barrier after the build loop and the store loop.  patch(j, c, idx) stores the
+// final pool index into the entry of (bucket j of this phase, symbol c).
+template <class Patch>
+__device__ __forceinline__ void sm_dense_flush(SmDense &D, const u8 *sym, i64 base, i64 m, int first_bucket, u32 *pool, u32 *pool_cursor,
+                                               u32 pool_cap, int *err, Patch patch) {
+  __syncthreads();
+  const u32 nd = D.n < SM_DENSE_CAP ? D.n : SM_DENSE_CAP;
+  if (threadIdx.x == 0) {
+    if (D.n > SM_DENSE_CAP) *err = 1;
+    D.base = nd ? atomicAdd(pool_cursor, nd) : 0u;
+  }
+  __syncthreads();
+  const u32 pbase = D.base;
+  const int w = threadIdx.x & 7;
+  for (u32 it = threadIdx.x >> 3; it < nd; it += 32) {
+    const u32 j = D.item[it] >> 8, c = D.item[it] & 255u, idx = pbase + it;
+    if (idx < pool_cap) {
+      const u32 *bs = (const u32 *)(sym + (first_bucket + (int)j) * 256) + w * 8;
+      const u32 c4 = c * 0x01010101u;
+      u32 bits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bits |= sm_eq_nibble(bs[k], c4) << (4 * k);
+      const i64 lim = m - (base + (first_bucket + (int)j) * 256) - 32 * w;   // valid positions from this word on
+      if (lim < 32) bits &= lim <= 0 ? 0u : ((1u << lim) - 1u);
+      pool[(size_t)idx * 8 + w] = bits;
+    } else *err = 1;
+    if (w == 0) patch((int)j, (int)c, idx);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) D.n = 0;
+}
+
+// L8: the LIST symbols of this structure use 8-byte entries (SM_LIST8) -- all of them or none
+template <bool L8>
 __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, const u64 *t2g, const u32 *seg_pref, const u64 *group_base,
                                                        uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err) {
   __shared__ __attribute__((aligned(16))) u8 sym[SM_SEG];
@@ -83,12 +144,13 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   __shared__ u64 t2S[256];
   __shared__ u8 bmSym[SM_MAX_BITMAP];            // symbols in BITMAP mode
   __shared__ int nbm;
+  __shared__ SmDense D;
   const int c = threadIdx.x;
   const i64 seg = blockIdx.x, base = seg * SM_SEG;
   const u64 t2 = t2g[c];
   const u32 mymode = (u32)(t2 >> SM_MODE_SHIFT);
   t2S[c] = t2;
-  if (c == 0) nbm = 0;
+  if (c == 0) { nbm = 0; D.n = 0; }
   if (base + SM_SEG <= m && ((uintptr_t)bwt & 15) == 0) {
     ((uint4 *)sym)[c] = ((const uint4 *)(bwt + base))[c];
   } else {
@@ -97,9 +159,47 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   __syncthreads();
   if (mymode == SM_BITMAP) { int k = atomicAdd(&nbm, 1); if (k < SM_MAX_BITMAP) bmSym[k] = (u8)c; }
   u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c]);
-  const u32 c4 = (u32)c * 0x01010101u;
+  // ---------------- LIST8 symbols: one phase over the 16 buckets, runs of 16 entries = one 128-byte line ----------------
+  if (L8) {
+    for (int k = c; k < 16 * SM_OUT_STRIDE; k += 256) P.L8.slot[k] = make_uint2(0u, ~0u);
+    __syncthreads();
+    for (int j = 0; j < 16; ++j) {
+      int q = j * 256 + c;
+      if (base + q < m) {
+        u32 s = sym[q];
+        if ((u32)(t2S[s] >> SM_MODE_SHIFT) == SM_LIST8) {
+          uint2 *sl = &P.L8.slot[j * SM_OUT_STRIDE + s];
+          u32 k = atomicAdd(&sl->x, 1u);
+          if (k < SM_CAP8) ((u8 *)sl)[4 + k] = (u8)c;
+        }
+      }
+    }
+    __syncthreads();
+    if (mymode == SM_LIST8) {
+      for (int j = 0; j < 16; ++j) {
+        const uint2 raw = P.L8.slot[j * SM_OUT_STRIDE + c];
+        const u32 n = raw.x;
+        uint2 e = make_uint2(run, raw.y);
+        if (n > SM_CAP8) {   // dense bucket: 256-bit bitmap in the overflow pool (index patched in by sm_dense_flush)
+          u32 k = atomicAdd(&D.n, 1u);
+          if (k < SM_DENSE_CAP) D.item[k] = (u16)((j << 8) | c);
+          e = make_uint2(run | 0x80000000u, 0u);
+        }
+        P.L8.slot[j * SM_OUT_STRIDE + c] = e;
+        run += n;
+      }
+    }
+    sm_dense_flush(D, sym, base, m, 0, pool, pool_cursor, pool_cap, err, [&](int j, int cc, u32 idx) { P.L8.slot[j * SM_OUT_STRIDE + cc].y = idx; });
+    for (int idx = c; idx < 256 * 16; idx += 256) {   // 16 consecutive lanes write the 16 entries of one symbol
+      int s = idx >> 4, j = idx & 15;
+      u64 ts = t2S[s];
+      i64 bk = seg * 16 + j;
+      if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST8 && bk * 256 < m) ((uint2 *)(entries + (ts & SM_OFF_MASK)))[bk] = P.L8.slot[j * SM_OUT_STRIDE + s];
+    }
+    __syncthreads();
+  }
   // ---------------- LIST symbols: 16/SM_NB phases of SM_NB buckets ----------------
-  for (int ph = 0; ph < 16 / SM_NB; ++ph) {
+  for (int ph = 0; !L8 && ph < 16 / SM_NB; ++ph) {
     for (int k = c; k < SM_NB * SM_OUT_STRIDE; k += 256) P.L.slot[k] = make_uint4(0u, ~0u, ~0u, ~0u);
     __syncthreads();
     for (int j = 0; j < SM_NB; ++j) {
@@ -124,26 +224,16 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
           e.y = n | (raw.y << 8);
           e.z = (raw.y >> 24) | (raw.z << 8);
           e.w = (raw.z >> 24) | (raw.w << 8);
-        } else {   // dense bucket: 256-bit bitmap in the overflow pool
-          u32 idx = atomicAdd(pool_cursor, 1u);
-          e.y = 0xFFu; e.z = idx; e.w = 0;
-          if (idx < pool_cap) {
-            const u8 *bs = sym + (ph * SM_NB + j) * 256;
-            i64 lim = m - (base + (ph * SM_NB + j) * 256);
-            for (int k = 0; k < 8; ++k) {
-              u32 bits = 0;
-              for (int w = 0; w < 8; ++w) bits |= sm_eq_nibble(((const u32 *)bs)[k * 8 + w], c4) << (4 * w);
-              int rem = (int)std::min<i64>(lim - 32 * k, 32);
-              if (rem < 32) bits &= rem <= 0 ? 0u : ((1u << rem) - 1u);
-              pool[(size_t)idx * 8 + k] = bits;
-            }
-          } else *err = 1;
+        } else {   // dense bucket: 256-bit bitmap in the overflow pool (index patched in by sm_dense_flush)
+          u32 k = atomicAdd(&D.n, 1u);
+          if (k < SM_DENSE_CAP) D.item[k] = (u16)((j << 8) | c);
+          e.y = 0xFFu; e.z = 0; e.w = 0;
         }
         P.L.slot[j * SM_OUT_STRIDE + c] = e;
         run += n;
       }
     }
-    __syncthreads();
+    sm_dense_flush(D, sym, base, m, ph * SM_NB, pool, pool_cursor, pool_cap, err, [&](int j, int cc, u32 idx) { P.L.slot[j * SM_OUT_STRIDE + cc].z = idx; });
     for (int idx = c; idx < 256 * SM_NB; idx += 256) {   // SM_NB consecutive lanes write consecutive entries of one symbol
       int s = idx / SM_NB, j = idx % SM_NB;
       u64 ts = t2S[s];

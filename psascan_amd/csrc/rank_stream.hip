@@ -13,6 +13,7 @@
 #include "dev_common.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -162,7 +163,8 @@ __device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 
     if (mode == SM_ABSENT) return;
     const uint4 *E = (const uint4 *)R.blocks + (t2 & SM_OFF_MASK);
     bool bm = mode == SM_BITMAP;
-    q.e = E[bm ? (i >> 6) : (i >> 8)];
+    if (mode == SM_LIST8) { uint2 x = ((const uint2 *)E)[i >> 8]; q.e = make_uint4(x.x, x.y, 0u, 0u); }
+    else q.e = E[bm ? (i >> 6) : (i >> 8)];
     q.off = (u32)i & (bm ? 63u : 255u);
     q.t2 = t2;
     q.kind = 1;
@@ -648,24 +650,39 @@ static void launch_build(const u8 *d_bwt, i64 m, const u8 *d_code, u32 *seg_cnt,
 
 // Symbol-major layout (rank_sm.hpp).  *fell_back = true: not applicable / did not fit / overflow
 // pool exhausted -- the caller builds a block layout instead.
-static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double budget_bytes, bool *fell_back) {
+static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double budget_bytes, bool allow_list8, bool *fell_back, bool *list8_failed) {
   *fell_back = true;
   if (m >= 0xFFFFFFFFll) return 0;
-  // per-symbol mode: BITMAP (bucket 64) when a 256-bucket would hold > 3 occurrences on average
+  // per-symbol mode: BITMAP (bucket 64) when a 256-bucket would hold > 3 occurrences on average; the other
+  // symbols get 8-byte LIST8 entries (4 positions inline) if every one of them averages <= 1.5 per bucket
+  // -- a byte-uniform text: 8 instead of 16 bytes of structure per symbol -- else 16-byte LIST entries
   u64 off16 = 0;
   u64 t2[256];
   int nbitmap = 0;
-  for (int c = 0; c < 256; ++c) nbitmap += h[c] && (double)h[c] * 256.0 > 3.0 * (double)m;
+  bool list8 = allow_list8 && !(getenv("PSG_SM_LIST8") && !strcmp(getenv("PSG_SM_LIST8"), "0"));
+  *list8_failed = false;
+  double dense8 = 0;   // expected number of LIST8 buckets with more than 4 occurrences (Poisson)
+  for (int c = 0; c < 256; ++c) {
+    if (!h[c]) continue;
+    const double lam = (double)h[c] * 256.0 / (double)m;
+    if (lam > 3.0) { ++nbitmap; continue; }
+    if (lam > 1.5) list8 = false;
+    double p = std::exp(-lam), tail = 1.0 - p;
+    for (int k = 1; k <= SM_CAP8; ++k) { p *= lam / k; tail -= p; }
+    dense8 += std::max(0.0, tail) * (double)cdiv(m, 256);
+  }
   if (nbitmap > SM_MAX_BITMAP) return 0;   // too many frequent symbols for the fill kernel's LDS budget
   for (int c = 0; c < 256; ++c) {
     if (!h[c]) { t2[c] = 0; continue; }
     bool bitmap = (double)h[c] * 256.0 > 3.0 * (double)m;
     u64 nbk = bitmap ? (u64)cdiv(m, 64) : (u64)cdiv(m, 256);
-    t2[c] = off16 | ((u64)(bitmap ? SM_BITMAP : SM_LIST) << SM_MODE_SHIFT);
+    if (!bitmap && list8) nbk = (nbk + 1) / 2;   // 8-byte entries, counted in 16-byte units
+    t2[c] = off16 | ((u64)(bitmap ? SM_BITMAP : (list8 ? SM_LIST8 : SM_LIST)) << SM_MODE_SHIFT);
     off16 += (nbk + 7) / 8 * 8;   // regions start on 128-byte lines (the fill kernel writes whole lines)
   }
   const i64 entries_bytes = (i64)off16 * 16;
-  const u32 pool_cap = (u32)std::max<i64>(1024, m / 512);   // 32-byte bitmaps for dense LIST buckets
+  // 32-byte bitmaps for dense buckets: LIST keeps 11 positions inline (dense = runs of one symbol); LIST8 keeps 4
+  const u32 pool_cap = (u32)std::min<double>(4.0e9, std::max<double>(1024.0, (double)m / 512.0 + (list8 ? 2.0 * dense8 + 65536.0 : 0.0)));
   if ((double)entries_bytes + 32.0 * pool_cap > budget_bytes) return 0;
   const i64 nseg = cdiv(m, SM_SEG), ngroups = cdiv(nseg, GROUP_SEGS);
   DevBuf code_d, seg_cnt, group_sum, t2_d, misc;
@@ -683,13 +700,19 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   hipLaunchKernelGGL((seg_hist_kernel<256, 64>), dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>());
   hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * 256, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt.as<u32>(), nseg, 256, group_sum.as<u64>(), ngroups);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
-  hipLaunchKernelGGL(sm_fill_kernel, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                     (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
+  if (list8) hipLaunchKernelGGL(sm_fill_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
+                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
+  else hipLaunchKernelGGL(sm_fill_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
+                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
   u32 st[2] = {0, 0};
   hipError_t e4 = hipGetLastError();
   if (e4 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4)); return fail(PSG_EDEVICE); }
   if ((rc = psg::copy_d2h(st, misc.p, 8))) return fail(rc);
-  if (st[1] || st[0] > pool_cap) { psg::pool_free(entries); psg::pool_free(pool); return 0; }   // too many dense buckets: block layout instead
+  if (st[1] || st[0] > pool_cap) {   // too many dense buckets (runs of a symbol): the caller retries with roomier entries, then blocks
+    psg::pool_free(entries); psg::pool_free(pool);
+    *list8_failed = list8;
+    return 0;
+  }
   r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = 1;
   r->d_blocks = entries; r->d_aux = pool; r->blocks_bytes = entries_bytes + (i64)pool_cap * 32;
   for (int c = 0; c < 256; ++c) { r->t2[c] = t2[c]; r->code[c] = (u8)c; }
@@ -727,8 +750,13 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
     if (want_sm) {
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
-      bool fell_back = true;
-      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), &fell_back);
+      bool fell_back = true, l8_failed = false;
+      static bool avoid_list8 = false;   // texts whose BWT has runs overflow the 4 inline positions: remembered for the next block
+      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), !avoid_list8, &fell_back, &l8_failed);
+      if (!rc && fell_back && l8_failed) {
+        avoid_list8 = true;
+        rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), false, &fell_back, &l8_failed);
+      }
       if (rc) { delete r; return rc; }
       if (!fell_back) {
         tm.stop();
