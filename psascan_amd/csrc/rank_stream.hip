@@ -751,10 +751,8 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       bool fell_back = true, l8_failed = false;
-      static bool avoid_list8 = false;   // texts whose BWT has runs overflow the 4 inline positions: remembered for the next block
-      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), !avoid_list8, &fell_back, &l8_failed);
-      if (!rc && fell_back && l8_failed) {
-        avoid_list8 = true;
+      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), true, &fell_back, &l8_failed);
+      if (!rc && fell_back && l8_failed) {   // a BWT with runs overflows the 4 inline positions: 16-byte entries (one failed fill ~ 10 ms)
         rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), false, &fell_back, &l8_failed);
       }
       if (rc) { delete r; return rc; }
