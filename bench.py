@@ -36,13 +36,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # HBM bytes per streamed suffix of the stream kernel, from the PMC passes committed in
 # profiles/r01_pmc_summary.csv: (FETCH_SIZE + WRITE_SIZE) * 1024 / 2^31, keyed by rank layout
 # (bytes of rank structure per BWT symbol):
-#   16.0 = symbol-major layout, rank-log mode: (1.407e8 + 9.06e6) KB -> 71.4 B/suffix
-#          (64 rank sector + 4 log + ~1 text + gt words; 75.0 before the 64-byte text blocks / 16-byte gt_out
-#          stores; the first version -- interleaved blocks B=64 with atomics -- moved 170.6 B/suffix)
-# Calibration (profiles/r01_membench.txt + same csv): FETCH_SIZE*1024 is exact for random
-# 16-byte loads (64 B per request) and reads 1/2 for wide coalesced streams on gfx950; this
-# kernel's traffic is random-sector traffic, so no correction is applied.
-PMC_TRAFFIC_B_PER_SUFFIX = {16.0: 71.4}
+#   8.3  = symbol-major layout with 8-byte entries, rank-log mode: (1.411e8 + 8.92e6) KB -> 71.5 B/suffix
+#          (64 rank sector + 4 log + ~1 text + gt words; 16-byte entries: 71.4; before the 64-byte text blocks /
+#          16-byte gt_out stores: 75.0; the first version -- interleaved blocks B=64 with atomics -- 170.6)
+PMC_TRAFFIC_B_PER_SUFFIX = {8.3: 71.5, 16.0: 71.4}
 
 
 def parse():
