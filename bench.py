@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--text", choices=["bytes", "dna"], default="bytes", help="bytes = configs[1] (the metric's workload); dna = sigma 4 (configs[3]'s alphabet) at the same size, for DESIGN.md")
     return ap.parse_args()
 
 
@@ -178,7 +179,7 @@ def main():
     mid = n // 2
     ls, rs = mid, n - mid
     t0 = time.time()
-    d_text = extras.gen_text(n, extras.MODE_BYTES255, 0, seed=2)
+    d_text = extras.gen_text(n, extras.MODE_DNA if args.text == "dna" else extras.MODE_BYTES255, 0, seed=2)
     Rh = extras.sort_halfblock(d_text, n, mid, n)
     Lh = extras.sort_halfblock(d_text, n, 0, mid)
     api.sync()
@@ -313,7 +314,7 @@ def main():
             "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/u32/u40 integer", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {n / 2 ** 30:.2f} GiB uniform random bytes 0..254 (sigma=255; byte 255 is reserved by the reference), one block = two {mid / 2 ** 30:.2f} GiB half-blocks, single pass A + merge",
+            "config": {"workload": (f"configs[1]: {n / 2 ** 30:.2f} GiB uniform random bytes 0..254 (sigma=255; byte 255 is reserved by the reference)" if args.text == "bytes" else f"{n / 2 ** 30:.2f} GiB uniform random DNA (sigma=4), not the metric's workload") + f", one block = two {mid / 2 ** 30:.2f} GiB half-blocks, single pass A + merge",
                        "text_bytes": n, "half_blocks": 2, "tail_sharding": f"dp{world}" if world > 1 else "none",
                        "chains": st.n_chains, "chain_len": st.chain_len, "rank_bytes_per_symbol": rk_bytes / ls},
             "gap_stream_suffixes_per_s": rs * 1.0 / (per["stream"] + per["comm"]) if world > 1 else stream_suffixes / per["stream"],

@@ -47,7 +47,7 @@ KINDS = ["rand255", "sig4z", "dna", "sig12", "alla", "fib", "per3", "zeros"]
 
 
 # ------------------------------------------------------------------ rank (a3)
-@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 1), (255, 32), (255, 64), (255, 128), (255, 256), (4, 0), (4, 1), (4, -64),
+@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 1), (255, 32), (255, 64), (255, 128), (255, 256), (4, 0), (4, 1), (4, 48), (4, -64), (12, 64),
                                           (12, 0), (12, 1), (2, 0), (1, 0), (1, 1), ("runs", 1), ("skew", 1)])
 @pytest.mark.parametrize("m", [1, 47, 48, 49, 64, 4095, 4096, 4097, 100003])
 def test_rank_query(A, sigma, layout, m):
