@@ -670,6 +670,68 @@ __global__ __launch_bounds__(PSG_WG, MWAVES) void merge_kernel(const MergeLevel 
   }
 }
 
+// Two half-blocks (one block): out[x] = bit ? psa1[rank1(x)] : psa0[rank0(x)].  No slot compaction in LDS:
+// a thread's 8 output slots take consecutive elements of the two arrays, so its gathers walk two short
+// runs (neighbouring lanes share sectors; the 8 loads are independent and issued together).
+template <bool HI>
+__global__ __launch_bounds__(PSG_WG) void merge2_kernel(MergeLevel L0, MergeLevel L1, i64 out_begin, i64 count, u8 *out) {
+  __shared__ u32 scratch[8];
+  __shared__ __attribute__((aligned(16))) u32 packed[MT * 5 / 4];
+  const i64 x0 = out_begin + (i64)blockIdx.x * MT;
+  const int len = (int)std::min<i64>(MT, out_begin + count - x0);
+  const int e0 = threadIdx.x * MEPT;
+  u32 bits, part;
+  i64 samp;
+  merge_level_loads(L0, x0, len, bits, part, samp);
+  const u32 part_tot = block_sum<u32>(part, scratch);
+  const i64 ones_q0 = samp + part_tot, zeros_q0 = x0 - ones_q0;
+  const int n = std::max(0, std::min(MEPT, len - e0));
+  u32 tot1;
+  const u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
+  const u32 *p1 = L1.lo + ones_q0 + o, *p0 = L0.lo + zeros_q0 + (e0 - (int)o);
+  const u8 *h1 = L1.hi ? L1.hi + ones_q0 + o : nullptr, *h0 = L0.hi ? L0.hi + zeros_q0 + (e0 - (int)o) : nullptr;
+  u32 lo[MEPT], hi[MEPT];
+#pragma unroll
+  for (int q = 0; q < MEPT; ++q) {
+    const bool one = (bits >> q) & 1u;
+    const int below1 = __popc(bits & ((1u << q) - 1u)), k = one ? below1 : q - below1;
+    lo[q] = 0; hi[q] = 0;
+    if (q < n) {
+      lo[q] = gload((one ? p1 : p0) + k);
+      if (HI) { const u8 *hp = one ? h1 : h0; hi[q] = hp ? gload(hp + k) : 0u; }
+    }
+  }
+  // values -> 40-bit little-endian (types/uint40.hpp:42-104), 8 entries = 10 dwords per thread, through LDS
+  u64 v[MEPT];
+#pragma unroll
+  for (int q = 0; q < MEPT; ++q) {
+    const bool one = (bits >> q) & 1u;
+    v[q] = (u64)(one ? L1.beg : L0.beg) + lo[q] + (HI ? ((u64)hi[q] << 32) : 0);
+  }
+  u32 *dst = packed + 10 * threadIdx.x;
+#pragma unroll
+  for (int g4 = 0; g4 < 2; ++g4) {
+    const u32 l0 = (u32)v[4 * g4], l1 = (u32)v[4 * g4 + 1], l2 = (u32)v[4 * g4 + 2], l3 = (u32)v[4 * g4 + 3];
+    const u32 b0 = (u32)(v[4 * g4] >> 32) & 255u, b1 = (u32)(v[4 * g4 + 1] >> 32) & 255u, b2 = (u32)(v[4 * g4 + 2] >> 32) & 255u,
+              b3 = (u32)(v[4 * g4 + 3] >> 32) & 255u;
+    dst[5 * g4 + 0] = l0;
+    dst[5 * g4 + 1] = b0 | (l1 << 8);
+    dst[5 * g4 + 2] = (l1 >> 24) | (b1 << 8) | (l2 << 16);
+    dst[5 * g4 + 3] = (l2 >> 16) | (b2 << 16) | (l3 << 24);
+    dst[5 * g4 + 4] = (l3 >> 8) | (b3 << 24);
+  }
+  __syncthreads();
+  u8 *obase = out + 5 * (x0 - out_begin);
+  const int nbytes = 5 * len, ndw = nbytes >> 2;
+  if (((uintptr_t)obase & 15) == 0) {
+    for (int k = threadIdx.x; k < (ndw >> 2); k += PSG_WG) ((uint4 *)obase)[k] = ((const uint4 *)packed)[k];
+    for (int k = (ndw & ~3) + threadIdx.x; k < ndw; k += PSG_WG) ((u32 *)obase)[k] = packed[k];
+  } else {
+    for (int k = threadIdx.x; k < ndw; k += PSG_WG) ((u32 *)obase)[k] = packed[k];
+  }
+  for (int bb = 4 * ndw + threadIdx.x; bb < nbytes; bb += PSG_WG) obase[bb] = ((const u8 *)packed)[bb];   // ragged end of the last tile
+}
+
 extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
   if (!p) return;
   for (void *q : p->owned) psg::pool_free(q);
@@ -732,6 +794,16 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   bool any_hi = false;
   for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
+  if (p->H == 2 && !getenv("PSG_MERGE_GENERAL")) {   // one block: the two-way kernel
+    const unsigned g2 = (unsigned)cdiv(out_count, MT);
+    if (any_hi) hipLaunchKernelGGL(merge2_kernel<true>, dim3(g2), dim3(PSG_WG), 0, stream(), p->levels[0], p->levels[1], out_begin, out_count, d_out);
+    else hipLaunchKernelGGL(merge2_kernel<false>, dim3(g2), dim3(PSG_WG), 0, stream(), p->levels[0], p->levels[1], out_begin, out_count, d_out);
+    PSG_HIP(hipGetLastError());
+    tm.stop();
+    PSG_HIP(psg::sync_stream());
+    note_kernel_ms(tm.ms());
+    return 0;
+  }
   auto kern = any_hi ? merge_kernel<true> : merge_kernel<false>;
   int per_cu = 0;   // persistent grid = what is resident at once
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PSG_WG, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
