@@ -508,32 +508,6 @@ struct psg_merge_plan {
 //#define MT 2048                 // output slots per merge tile: 18 KiB of LDS -> 8 workgroups per CU (a tile is a chain of
 #define MEPT (MT / PSG_WG)      // dependent loads, so the kernel is latency-bound: residency matters more than tile size)
 
-// PSA values of a contiguous range [first, first+cnt), cnt <= MT: eight independent loads per thread
-template <bool HI>
-__device__ __forceinline__ void merge_load(const MergeLevel &L, i64 first, int cnt, u32 (&lo)[MEPT], u32 (&hi)[MEPT]) {
-  const u32 *plo = L.lo + first + threadIdx.x;
-  const u8 *phi = L.hi + first + threadIdx.x;
-#pragma unroll
-  for (int u = 0; u < MEPT; ++u) {
-    int i = u * PSG_WG + threadIdx.x;
-    lo[u] = i < cnt ? gload(plo + u * PSG_WG) : 0;
-    if (HI) hi[u] = (i < cnt && L.hi) ? gload(phi + u * PSG_WG) : 0;
-  }
-}
-// element i goes to output slot slots[dir * i] (slot i when slots is null)
-template <bool HI>
-__device__ __forceinline__ void merge_scatter(i64 beg, int cnt, const u32 (&lo)[MEPT], const u32 (&hi)[MEPT], const u16 *slots, int dir,
-                                              u32 *vlo, u8 *vhi) {
-#pragma unroll
-  for (int u = 0; u < MEPT; ++u) {
-    int i = u * PSG_WG + threadIdx.x;
-    if (i < cnt) {
-      int slot = slots ? slots[dir * i] : i;
-      u64 v = (u64)beg + lo[u] + (HI ? ((u64)hi[u] << 32) : 0);
-      vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
-    }
-  }
-}
 // everything a level needs from memory for the range [q0, q0+cnt) of its merge bitvector: the
 // thread's MEPT bits, its share of the partial popcount in front of q0, the group's rank sample
 __device__ __forceinline__ void merge_level_loads(const MergeLevel &L, i64 q0, int cnt, u32 &bits, u32 &part, i64 &samp) {
@@ -555,118 +529,103 @@ __device__ __forceinline__ void merge_level_loads(const MergeLevel &L, i64 q0, i
   samp = (i64)gload(L.samp + g);
 }
 
-// Persistent workgroups, software-pipelined so that a tile exposes as few dependent memory
-// latencies as possible: the loads of the NEXT level (its bits, or its PSA values when it is the
-// last one) are issued together with this level's own PSA loads, and the first level of the next
-// tile is requested before this tile is packed and stored.
-// HI: some half-block has a high byte plane (texts of 4 GiB and more)
+// General case (H half-blocks).  A tile of MT output slots walks down the levels; a thread owns 8 consecutive
+// positions of the current level: its own elements (bit 0) are consecutive elements of this half-block's PSA
+// and are gathered straight into the output slots, its survivors (bit 1) are compacted -- slot numbers only --
+// into the other slot buffer and form a contiguous range of the next level.
 template <bool HI>
-#ifndef MWAVES
-#define MWAVES 4
-#endif
-__global__ __launch_bounds__(PSG_WG, MWAVES) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out, i64 ntiles) {
+__global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out) {
   __shared__ u32 scratch[8];
   __shared__ __attribute__((aligned(16))) u16 cur[2][MT];
-  __shared__ u32 vlo[MT];
+  __shared__ __attribute__((aligned(16))) u32 vlo[MT];
   __shared__ u8 vhi[MT];
   const int e0 = threadIdx.x * MEPT;
-  const MergeLevel L0 = lv[0];
-  u32 bits = 0, part = 0;
-  i64 samp = 0;
-  i64 tile = blockIdx.x;
-  if (tile < ntiles && H > 1) {
-    i64 x0 = out_begin + tile * MT;
-    merge_level_loads(L0, x0, (int)std::min<i64>(MT, out_begin + count - x0), bits, part, samp);
-  }
-  for (; tile < ntiles; tile += gridDim.x) {
-    const i64 x0 = out_begin + tile * MT;
-    const int len = (int)std::min<i64>(MT, out_begin + count - x0);
-    i64 q0 = x0;
-    int cnt = len, s = 0;
-    bool identity = true;
-    MergeLevel Lh = L0;
-    u32 lo[MEPT], hi[MEPT], lo2[MEPT], hi2[MEPT];
-    if (H == 1) {
-      merge_load<HI>(Lh, q0, cnt, lo, hi);
-      merge_scatter<HI>(Lh.beg, cnt, lo, hi, nullptr, 1, vlo, vhi);
-    } else {
-      for (int h = 0;; ++h) {   // invariant: h < H-1, cnt > 0, (bits, part, samp) loaded for (Lh, q0, cnt)
-        const MergeLevel Ln = lv[h + 1];
-        const bool next_last = h + 2 == H;
-        u32 part_tot = block_sum<u32>(part, scratch);
-        const i64 ones_q0 = samp + part_tot, zeros_q0 = q0 - ones_q0;
-        const int n = std::max(0, std::min(MEPT, cnt - e0));
-        u32 tot1;
-        const u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
-        const int nown = cnt - (int)tot1, ncnt = (int)tot1;
-        // every load that is addressable now: own elements of this level + the next level's input
-        merge_load<HI>(Lh, zeros_q0, nown, lo, hi);
-        u32 nbits = 0, npart = 0;
-        i64 nsamp = 0;
-        if (ncnt > 0) {
-          if (next_last) merge_load<HI>(Ln, ones_q0, ncnt, lo2, hi2);
-          else merge_level_loads(Ln, ones_q0, ncnt, nbits, npart, nsamp);
+  const i64 x0 = out_begin + (i64)blockIdx.x * MT;
+  const int len = (int)std::min<i64>(MT, out_begin + count - x0);
+  i64 q0 = x0;
+  int cnt = len, s = 0;
+  bool identity = true;
+  for (int h = 0; h < H && cnt > 0; ++h) {
+    const MergeLevel L = lv[h];
+    const int n = std::max(0, std::min(MEPT, cnt - e0));
+    if (h == H - 1) {   // last half-block: everything left is its own, in order
+      const u32 *p = L.lo + q0 + e0;
+      const u8 *ph = L.hi ? L.hi + q0 + e0 : nullptr;
+      u32 lo[MEPT], hi[MEPT];
+#pragma unroll
+      for (int q = 0; q < MEPT; ++q) { lo[q] = q < n ? gload(p + q) : 0u; hi[q] = (HI && ph && q < n) ? gload(ph + q) : 0u; }
+#pragma unroll
+      for (int q = 0; q < MEPT; ++q)
+        if (q < n) {
+          const int slot = identity ? e0 + q : cur[s][e0 + q];
+          const u64 v = (u64)L.beg + lo[q] + (HI ? ((u64)hi[q] << 32) : 0);
+          vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
         }
-        // survivors (bit 1) are compacted to the front of the other slot buffer, own elements (bit 0)
-        // to its back, so that both are handled by coalesced loops (own element i <-> PSA index zeros_q0 + i)
-        const int z = e0 - (int)o;
-        for (int q = 0; q < n; ++q) {
-          int slot = identity ? e0 + q : cur[s][e0 + q];
-          int below = __popc(bits & ((1u << q) - 1u));
-          if ((bits >> q) & 1u) cur[s ^ 1][o + below] = (u16)slot;
-          else cur[s ^ 1][MT - 1 - (z + q - below)] = (u16)slot;
+      break;
+    }
+    u32 bits, part;
+    i64 samp;
+    merge_level_loads(L, q0, cnt, bits, part, samp);
+    const u32 part_tot = block_sum<u32>(part, scratch);
+    const i64 ones_q0 = samp + part_tot, zeros_q0 = q0 - ones_q0;
+    u32 tot1;
+    const u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
+    const u32 *p = L.lo + zeros_q0 + (e0 - (int)o);
+    const u8 *ph = L.hi ? L.hi + zeros_q0 + (e0 - (int)o) : nullptr;
+    u32 lo[MEPT], hi[MEPT];
+#pragma unroll
+    for (int q = 0; q < MEPT; ++q) {   // the gathers of the own elements, issued together
+      const bool own = q < n && !((bits >> q) & 1u);
+      const int k = q - __popc(bits & ((1u << q) - 1u));
+      lo[q] = own ? gload(p + k) : 0u;
+      hi[q] = (HI && own && ph) ? gload(ph + k) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < MEPT; ++q)
+      if (q < n) {
+        const int slot = identity ? e0 + q : cur[s][e0 + q];
+        if ((bits >> q) & 1u) cur[s ^ 1][o + __popc(bits & ((1u << q) - 1u))] = (u16)slot;
+        else {
+          const u64 v = (u64)L.beg + lo[q] + (HI ? ((u64)hi[q] << 32) : 0);
+          vlo[slot] = (u32)v; vhi[slot] = (u8)(v >> 32);
         }
-        __syncthreads();
-        merge_scatter<HI>(Lh.beg, nown, lo, hi, cur[s ^ 1] + MT - 1, -1, vlo, vhi);
-        if (ncnt == 0) break;
-        if (next_last) { merge_scatter<HI>(Ln.beg, ncnt, lo2, hi2, cur[s ^ 1], 1, vlo, vhi); break; }
-        __syncthreads();
-        q0 = ones_q0; cnt = ncnt; s ^= 1; identity = false;
-        Lh = Ln; bits = nbits; part = npart; samp = nsamp;
       }
+    __syncthreads();
+    q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
+  }
+  __syncthreads();
+  // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords, staged in LDS (the slot
+  // buffers are dead now) so that the tile leaves as whole 16-byte stores
+  u32 *packed = (u32 *)&cur[0][0];                 // 8 KiB: half a tile (1024 entries = 5 KiB) at a time
+  u8 *obase = out + 5 * (x0 - out_begin);
+  const bool al16 = ((uintptr_t)obase & 15) == 0;
+  for (int eb = 0; eb < len; eb += MT / 2) {
+    const int ne = std::min(MT / 2, len - eb), nq = ne >> 2;
+    if (eb) __syncthreads();
+    for (int g4 = threadIdx.x; g4 < nq; g4 += PSG_WG) {
+      int e = eb + 4 * g4;
+      u32 l0 = vlo[e], l1 = vlo[e + 1], l2 = vlo[e + 2], l3 = vlo[e + 3];
+      u32 h0 = vhi[e], h1 = vhi[e + 1], h2 = vhi[e + 2], h3 = vhi[e + 3];
+      u32 *dst = packed + 5 * g4;
+      dst[0] = l0;
+      dst[1] = h0 | (l1 << 8);
+      dst[2] = (l1 >> 24) | (h1 << 8) | (l2 << 16);
+      dst[3] = (l2 >> 16) | (h2 << 16) | (l3 << 24);
+      dst[4] = (l3 >> 8) | (h3 << 24);
     }
     __syncthreads();
-    {   // request the first level of this workgroup's next tile before packing this one
-      i64 nt = tile + gridDim.x;
-      if (nt < ntiles && H > 1) {
-        i64 nx0 = out_begin + nt * MT;
-        merge_level_loads(L0, nx0, (int)std::min<i64>(MT, out_begin + count - nx0), bits, part, samp);
-      }
+    u32 *dst = (u32 *)(obase + 5 * eb);            // 5 * 1024 bytes per half: keeps the 16-byte alignment
+    const int ndw = nq * 5;
+    if (al16) {
+      for (int k = threadIdx.x; k < (ndw >> 2); k += PSG_WG) ((uint4 *)dst)[k] = ((const uint4 *)packed)[k];
+      for (int k = (ndw & ~3) + threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
+    } else {
+      for (int k = threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
     }
-    // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords, staged in LDS (the
-    // slot buffers are dead now) so that the tile leaves as whole 16-byte/256-byte coalesced stores
-    u32 *packed = (u32 *)&cur[0][0];                 // 8 KiB: half a tile (1024 entries = 5 KiB) at a time
-    u8 *obase = out + 5 * (x0 - out_begin);
-    const bool al16 = ((uintptr_t)obase & 15) == 0;
-    for (int eb = 0; eb < len; eb += MT / 2) {
-      const int ne = std::min(MT / 2, len - eb), nq = ne >> 2;
-      if (eb) __syncthreads();
-      for (int g4 = threadIdx.x; g4 < nq; g4 += PSG_WG) {
-        int e = eb + 4 * g4;
-        u32 l0 = vlo[e], l1 = vlo[e + 1], l2 = vlo[e + 2], l3 = vlo[e + 3];
-        u32 h0 = vhi[e], h1 = vhi[e + 1], h2 = vhi[e + 2], h3 = vhi[e + 3];
-        u32 *dst = packed + 5 * g4;
-        dst[0] = l0;
-        dst[1] = h0 | (l1 << 8);
-        dst[2] = (l1 >> 24) | (h1 << 8) | (l2 << 16);
-        dst[3] = (l2 >> 16) | (h2 << 16) | (l3 << 24);
-        dst[4] = (l3 >> 8) | (h3 << 24);
-      }
-      __syncthreads();
-      u32 *dst = (u32 *)(obase + 5 * eb);            // 5 * 1024 bytes per half: keeps the 16-byte alignment
-      const int ndw = nq * 5;
-      if (al16) {
-        for (int k = threadIdx.x; k < (ndw >> 2); k += PSG_WG) ((uint4 *)dst)[k] = ((const uint4 *)packed)[k];
-        for (int k = (ndw & ~3) + threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
-      } else {
-        for (int k = threadIdx.x; k < ndw; k += PSG_WG) dst[k] = packed[k];
-      }
-      for (int bb = nq * 20 + threadIdx.x; bb < 5 * ne; bb += PSG_WG) {   // ragged tail of the last tile
-        int e = eb + bb / 5, rr = bb % 5;
-        obase[5 * eb + bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
-      }
+    for (int bb = nq * 20 + threadIdx.x; bb < 5 * ne; bb += PSG_WG) {   // ragged tail of the last tile
+      int e = eb + bb / 5, rr = bb % 5;
+      obase[5 * eb + bb] = (u8)(rr < 4 ? (vlo[e] >> (8 * rr)) & 255u : vhi[e]);
     }
-    __syncthreads();   // vlo/vhi/cur are reused by the next tile
   }
 }
 
@@ -788,10 +747,6 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
   PSG_REQUIRE(((uintptr_t)d_out & 3) == 0, "psg_merge_run: output must be 4-byte aligned");
   if (out_count == 0) return 0;
   EventTimer tm; tm.start();
-  const i64 ntiles = cdiv(out_count, MT);
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   bool any_hi = false;
   for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
   if (p->H == 2 && !getenv("PSG_MERGE_GENERAL")) {   // one block: the two-way kernel
@@ -804,11 +759,9 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
     note_kernel_ms(tm.ms());
     return 0;
   }
-  auto kern = any_hi ? merge_kernel<true> : merge_kernel<false>;
-  int per_cu = 0;   // persistent grid = what is resident at once
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PSG_WG, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
-  const unsigned grid = (unsigned)std::min<i64>(ntiles, (i64)cus * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out, ntiles);
+  const unsigned grid = (unsigned)cdiv(out_count, MT);
+  if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
+  else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());
