@@ -239,11 +239,21 @@ __global__ __launch_bounds__(PSG_WG) void seg_hist_kernel(const u8 *bwt, i64 m, 
   for (int k = threadIdx.x; k < CNT; k += PSG_WG) h[k] = 0;
   __syncthreads();
   i64 base = (i64)blockIdx.x * SEGSYM;
-  for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) {
-    i64 p = base + k;
-    if (p < m) {
-      u32 cd = code[bwt[p]];
+  if (SEGSYM == 16 * PSG_WG && base + SEGSYM <= m && ((uintptr_t)bwt & 15) == 0) {   // whole segment: one 16-byte load per thread
+    const uint4 v = ((const uint4 *)(bwt + base))[threadIdx.x];
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      u32 cd = code[(w[k >> 2] >> (8 * (k & 3))) & 255u];
       if (cd != 0xFFu) atomicAdd(&h[cd], 1u);
+    }
+  } else {
+    for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) {
+      i64 p = base + k;
+      if (p < m) {
+        u32 cd = code[bwt[p]];
+        if (cd != 0xFFu) atomicAdd(&h[cd], 1u);
+      }
     }
   }
   __syncthreads();
