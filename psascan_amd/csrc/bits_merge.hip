@@ -20,6 +20,17 @@ using namespace psg;
 // =======================================================================================
 // small kernels shared by several entry points
 // =======================================================================================
+// g[q] = v[base + q] for base + q < n (else 0): two 16-byte loads when the group is whole and v is 16-byte aligned
+__device__ __forceinline__ void load8_u32(const u32 *v, i64 base, i64 n, u32 (&g)[8]) {
+  if (base + 8 <= n && ((uintptr_t)v & 15) == 0) {
+    const uint4 a = *(const uint4 *)(v + base), b = *(const uint4 *)(v + base + 4);
+    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] = base + q < n ? v[base + q] : 0u;
+  }
+}
+
 __global__ __launch_bounds__(PSG_WG) void tile_sum_u32_kernel(const u32 *v, i64 n, u64 *tile_sum) {
   __shared__ u64 scratch[8];
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
@@ -321,8 +332,10 @@ __global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, co
   __shared__ u64 scratch[8];
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u64 s = 0;
+  u32 g[8];
+  load8_u32(gap, base, block + 1, g);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) if (base + q <= block) s += gap[base + q];
+  for (int q = 0; q < 8; ++q) s += g[q];
   int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
   u32 bits = n > 0 ? get_bits(bv, base, n, (block + 31) >> 5) : 0;
   u64 tg = block_sum<u64>(s, scratch);
@@ -337,8 +350,9 @@ __global__ __launch_bounds__(PSG_WG) void split_apply_kernel(const u32 *gap, con
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u32 g[8];
   u64 s = 0;
+  load8_u32(gap, base, block + 1, g);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { g[q] = base + q <= block ? gap[base + q] : 0; s += g[q]; }
+  for (int q = 0; q < 8; ++q) s += g[q];
   int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
   u32 bits = n > 0 ? get_bits(bv, base, n, (block + 31) >> 5) : 0;
   u64 t0, t1;
