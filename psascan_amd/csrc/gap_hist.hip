@@ -4,11 +4,14 @@
 //
 // The stream kernel (MODE 2) logs the rank of every streamed suffix with coalesced stores.  Here
 // the log is partitioned so that every WINDOW of 2^WBITS consecutive gap counters becomes one
-// contiguous piece of it, and each window is histogrammed in LDS and added to the gap array with
-// coalesced read-modify-writes.  The partition is a hand-written two-level MSD radix split
-// (<= 512 bins per level) with deterministic offsets: persistent workgroups own private output
-// cursors, so there are no global atomics and no ordering requirements; tiles are staged in LDS
-// and written as per-bin runs.  (The reference does the same thing for cache locality on the CPU:
+// contiguous piece of it, and each window is histogrammed in LDS and added to (or, for a fresh gap
+// array, stored into) the gap array with coalesced 16-byte accesses.  The partition is a
+// hand-written two-level MSD radix split (<= 512 bins per level) with deterministic offsets: a
+// count pass gives every workgroup private output segments, so there are no global atomics and no
+// ordering requirements.  Two versions live here: the exact-size scatter (tiles staged in LDS, written
+// as per-bin runs) behind psg_log_partition, whose output goes over the wire, and "partition v2"
+// (per-bin staging in LDS across tiles, whole 64-byte units only, padded segments) behind the
+// histogram path.  (The reference does the same thing for cache locality on the CPU:
 // stream.hpp:160-232 buckets every buffer of ranks by value range before the updaters run.)
 #include "dev_common.hpp"
 

@@ -1,6 +1,8 @@
 // rank_stream.hip -- K1 (rank structure build) and K2 (streaming gap kernel) for gfx950.
 //
-// Rank layout ("interleaved blocks", HBM-resident): the BWT is cut into blocks of B data
+// Default rank layout: symbol-major entries, one 8/16-byte load per query (rank_sm.hpp).  Fallback for
+// blocks of >= 2^32 - 1 symbols, or when that structure does not fit the HBM budget:
+// "interleaved blocks" (HBM-resident): the BWT is cut into blocks of B data
 // bytes; each block is stored as  [CNT x u32 counters][B data bytes]  (STRIDE = 4*CNT+B).
 // counter[code] = #occurrences of that symbol before the block, relative to the enclosing
 // superblock (2^SB_SHIFT blocks); the superblock bases (u64) are folded with the C array of
