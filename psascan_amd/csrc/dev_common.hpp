@@ -17,7 +17,13 @@ namespace psg {
 
 // ---- error plumbing ------------------------------------------------------------------
 void set_error(const std::string &s);
-hipStream_t stream();
+hipStream_t stream();                       // the stream every launch of the library goes to
+hipStream_t side_stream();                  // a second stream for work that overlaps the main one (created on first use)
+struct StreamScope {                        // within the scope, stream() is `s`
+  hipStream_t prev;
+  explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+};
 void note_kernel_ms(double ms);
 
 #define PSG_HIP(call)                                                                        \
@@ -94,6 +100,16 @@ static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
 // LDS-sized windows -- replaces one random atomic per streamed suffix (gap_hist.hip).
 // overwrite: d_gap holds garbage on entry and exactly the histogram on return (no zero-fill needed)
 int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
+// the same in two halves: launch enqueues everything on stream() without waiting for the device, wait
+// blocks until the job is done, checks the overflow flag and releases the job's buffers
+struct HistJob {
+  DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot, ovf;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipStream_t s = nullptr;
+  bool active = false;
+};
+int gap_hist_launch(HistJob &job, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite);
+int gap_hist_wait(HistJob &job, double *ms);
 
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);

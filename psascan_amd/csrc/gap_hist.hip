@@ -398,10 +398,11 @@ __global__ __launch_bounds__(PSG_WG) void zero_multi_item_windows_kernel(const u
 // 512 threads: the 64 KiB histogram allows two workgroups per CU, and the kernel needs loads in flight
 #define HWG 512
 template <bool OVERWRITE>
-__global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, i64 nwin, i64 m, u32 *gap, int *ovf) {
+__global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, const u64 *n_items, i64 nwin, i64 m, u32 *gap, int *ovf) {
   __shared__ __attribute__((aligned(16))) u32 h[WSIZE];
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
+  if (item >= (i64)*n_items) return;   // the grid is an upper bound (no host round trip for the item count)
   if (threadIdx.x == 0) {  // window of this item: last w with item_pref[w] <= item
     i64 lo = 0, hi = nwin;
     while (lo + 1 < hi) {
@@ -452,10 +453,11 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
   }
 }
 
-int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
+int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
   static_assert(P2T == PBINS, "p2_level2_kernel maps one sub-bin to one thread");
-  EventTimer tm;
-  tm.start();
+  J.s = stream();
+  J.ev_begin = event_acquire(); J.ev_end = event_acquire();
+  (void)hipEventRecord(J.ev_begin, J.s);
   const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18 for m < 2^32
   // level 2 only when there are > 512 windows: 511 level-1 bins of 2^bits2 windows + a top bin that takes the
   // rest (<= 512 windows).  m + 1 = 2^31 + 1 (a 2 GiB half-block) thus uses all 512 bins, not 257 of them.
@@ -467,47 +469,66 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, P2TS)));
   const i64 chunk = cdiv(cdiv(nlog, G), P2TS) * P2TS;
-  DevBuf part1, part2, counts, off, bin_base, win_off, cnt, tot, ovf;
   int rc;
-  if ((rc = ovf.alloc(4))) return rc;
-  PSG_HIP(hipMemsetAsync(ovf.p, 0, 4, stream()));
+  if ((rc = J.ovf.alloc(4))) return rc;
+  PSG_HIP(hipMemsetAsync(J.ovf.p, 0, 4, J.s));
   const i64 nwin_slots = (bits2 ? ((i64)PBINS << bits2) : PBINS) + PBINS + 2;
   const i64 cap1 = nlog + P2SLACK * G + 64;                 // level-1 output incl. the rounding of every (workgroup, bin) segment
-  if ((rc = part1.alloc(cap1 * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) ||
-      (rc = bin_base.alloc((PBINS + 1) * 8)) || (rc = win_off.alloc((nwin_slots + 1) * 8)) || (rc = cnt.alloc(nwin_slots * 8)) || (rc = tot.alloc(8)))
+  const i64 cap2 = cap1 + P2SLACK * (PBINS + 1);
+  if ((rc = J.part1.alloc(cap1 * 4)) || (rc = J.counts.alloc((i64)G * PBINS * 4)) || (rc = J.off.alloc((i64)G * PBINS * 8)) ||
+      (rc = J.bin_base.alloc((PBINS + 1) * 8)) || (rc = J.win_off.alloc((nwin_slots + 1) * 8)) || (rc = J.cnt.alloc(nwin_slots * 8)) || (rc = J.tot.alloc(8)))
     return rc;
-  hipLaunchKernelGGL(p2_count_kernel, dim3(G), dim3(P2T), 0, stream(), d_log, nlog, chunk, shift1, counts.as<u32>());
-  hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
-  hipLaunchKernelGGL(p2_scatter_kernel, dim3(G), dim3(P2T), 0, stream(), d_log, nlog, chunk, shift1, off.as<u64>(), part1.as<u32>());
+  hipLaunchKernelGGL(p2_count_kernel, dim3(G), dim3(P2T), 0, J.s, d_log, nlog, chunk, shift1, J.counts.as<u32>());
+  hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, J.s, J.counts.as<u32>(), G, J.off.as<u64>(), J.bin_base.as<u64>());
+  hipLaunchKernelGGL(p2_scatter_kernel, dim3(G), dim3(P2T), 0, J.s, d_log, nlog, chunk, shift1, J.off.as<u64>(), J.part1.as<u32>());
   PSG_HIP(hipGetLastError());
-  const u32 *sorted = part1.as<u32>();
-  const u64 *woff = bin_base.as<u64>();
+  const u32 *sorted = J.part1.as<u32>();
+  const u64 *woff = J.bin_base.as<u64>();
   if (bits2) {
-    if ((rc = part2.alloc((cap1 + P2SLACK * (PBINS + 1)) * 4))) return rc;
-    hipLaunchKernelGGL(p2_level2_kernel, dim3(PBINS), dim3(P2T), 0, stream(), part1.as<u32>(), bin_base.as<u64>(), bits2, nwin, part2.as<u32>(), win_off.as<u64>());
+    if ((rc = J.part2.alloc(cap2 * 4))) return rc;
+    hipLaunchKernelGGL(p2_level2_kernel, dim3(PBINS), dim3(P2T), 0, J.s, J.part1.as<u32>(), J.bin_base.as<u64>(), bits2, nwin, J.part2.as<u32>(), J.win_off.as<u64>());
     PSG_HIP(hipGetLastError());
-    sorted = part2.as<u32>();
-    woff = win_off.as<u64>();
+    sorted = J.part2.as<u32>();
+    woff = J.win_off.as<u64>();
   }
-  hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, stream(), woff, nwin, cnt.as<u64>(), overwrite ? 1 : 0);
-  if (overwrite) hipLaunchKernelGGL(zero_multi_item_windows_kernel, dim3((unsigned)nwin), dim3(PSG_WG), 0, stream(), woff, nwin, m, d_gap);
+  hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)cdiv(nwin, PSG_WG)), dim3(PSG_WG), 0, J.s, woff, nwin, J.cnt.as<u64>(), overwrite ? 1 : 0);
+  if (overwrite) hipLaunchKernelGGL(zero_multi_item_windows_kernel, dim3((unsigned)nwin), dim3(PSG_WG), 0, J.s, woff, nwin, m, d_gap);
   PSG_HIP(hipGetLastError());
-  if ((rc = scan_u64_inplace(cnt.as<u64>(), nwin, tot.as<u64>()))) return rc;
-  u64 items = 0;
-  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), tot.p, 8, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
-  PSG_HIP(psg::sync_stream());
-  memcpy(&items, pinned_buf(3, 64), 8);
-  if (items > 0) {
-    if (overwrite) hipLaunchKernelGGL(hist_items_kernel<true>, dim3((unsigned)items), dim3(HWG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
-    else hipLaunchKernelGGL(hist_items_kernel<false>, dim3((unsigned)items), dim3(HWG), 0, stream(), sorted, woff, cnt.as<u64>(), nwin, m, d_gap, ovf.as<int>());
-    PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(J.cnt.as<u64>(), nwin, J.tot.as<u64>()))) return rc;
+  // work items: one per window (overwrite) or per non-empty window, plus one per CAP entries; upper bound, the
+  // kernel reads the exact count on the device
+  const i64 items_max = nwin + (bits2 ? cap2 : cap1) / CAP + 1;
+  if (overwrite) hipLaunchKernelGGL(hist_items_kernel<true>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, J.ovf.as<int>());
+  else hipLaunchKernelGGL(hist_items_kernel<false>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, J.ovf.as<int>());
+  PSG_HIP(hipGetLastError());
+  (void)hipEventRecord(J.ev_end, J.s);
+  J.active = true;
+  return 0;
+}
+
+int psg::gap_hist_wait(HistJob &J, double *ms) {
+  if (!J.active) { if (ms) *ms = 0; return 0; }
+  J.active = false;
+  int h_ovf = 0, rc = 0;
+  {
+    StreamScope sc(J.s);
+    rc = psg::copy_d2h(&h_ovf, J.ovf.p, 4);   // orders behind the job on its stream and waits for it
   }
-  tm.stop();
-  int h_ovf = 0;
-  if ((rc = psg::copy_d2h(&h_ovf, ovf.p, 4))) return rc;
-  if (ms) *ms = tm.ms();
+  float f = 0;
+  (void)hipEventElapsedTime(&f, J.ev_begin, J.ev_end);
+  if (ms) *ms = f;
+  event_release(J.ev_begin); event_release(J.ev_end);
+  J.ev_begin = J.ev_end = nullptr;
+  J.part1.alloc(16); J.part2.alloc(16);     // give the big buffers back to the pool
+  if (rc) return rc;
   if (h_ovf) { set_error("gap histogram: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
   return 0;
+}
+
+int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
+  HistJob job;
+  if (int rc = gap_hist_launch(job, d_log, nlog, m, d_gap, overwrite)) return rc;
+  return gap_hist_wait(job, ms);
 }
 
 // ---------------------------------------------------------------------------------------

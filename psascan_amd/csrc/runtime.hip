@@ -16,7 +16,14 @@ static bool g_inited = false;
 static double g_last_ms = 0;
 
 void set_error(const std::string &s) { g_err = s; }
-hipStream_t stream() { return g_stream; }
+static hipStream_t g_override = nullptr, g_side = nullptr;
+hipStream_t stream() { return g_override ? g_override : g_stream; }
+hipStream_t side_stream() {
+  if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_side = nullptr; }
+  return g_side;
+}
+StreamScope::StreamScope(hipStream_t s) : prev(g_override) { g_override = s; }
+StreamScope::~StreamScope() { g_override = prev; }
 void note_kernel_ms(double ms) { g_last_ms = ms; }
 
 // ---- caching allocator ------------------------------------------------------------------
@@ -74,7 +81,7 @@ void pool_trim() {
     for (auto &kv : g_pool_free) blocks.push_back(kv.second);
     g_pool_free.clear();
   }
-  if (!blocks.empty() && g_stream) (void)hipStreamSynchronize(g_stream);
+  if (!blocks.empty() && g_stream) { (void)hipStreamSynchronize(g_stream); if (g_side) (void)hipStreamSynchronize(g_side); }
   for (void *b : blocks) (void)hipFree(b);
 }
 
@@ -98,8 +105,8 @@ void event_release(hipEvent_t e) {
 // ---- polling stream sync -----------------------------------------------------------------
 hipError_t sync_stream() {
   hipEvent_t e = event_acquire();
-  if (!e) return hipStreamSynchronize(g_stream);
-  hipError_t rc = hipEventRecord(e, g_stream);
+  if (!e) return hipStreamSynchronize(stream());
+  hipError_t rc = hipEventRecord(e, stream());
   if (rc == hipSuccess) {
     while ((rc = hipEventQuery(e)) == hipErrorNotReady) {
 #if defined(__x86_64__)
@@ -108,7 +115,7 @@ hipError_t sync_stream() {
     }
   }
   event_release(e);
-  if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamSynchronize(g_stream); }
+  if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamSynchronize(stream()); }
   return rc;
 }
 
@@ -134,7 +141,7 @@ int copy_h2d(void *d, const void *h, size_t bytes) {
     void *pin = pinned_buf(7, n);
     if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
     memcpy(pin, (const char *)h + off, n);
-    PSG_HIP(hipMemcpyAsync((char *)d + off, pin, n, hipMemcpyHostToDevice, g_stream));
+    PSG_HIP(hipMemcpyAsync((char *)d + off, pin, n, hipMemcpyHostToDevice, stream()));
     PSG_HIP(sync_stream());
   }
   return 0;
@@ -144,7 +151,7 @@ int copy_d2h(void *h, const void *d, size_t bytes) {
     size_t n = std::min(STAGE_BYTES, bytes - off);
     void *pin = pinned_buf(7, n);
     if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
-    PSG_HIP(hipMemcpyAsync(pin, (const char *)d + off, n, hipMemcpyDeviceToHost, g_stream));
+    PSG_HIP(hipMemcpyAsync(pin, (const char *)d + off, n, hipMemcpyDeviceToHost, stream()));
     PSG_HIP(sync_stream());
     memcpy((char *)h + off, pin, n);
   }
