@@ -202,6 +202,24 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+def test_stream_gap_ex_contract(A, gpu_lib):
+    """psg_stream_gap_ex: unknown flags are rejected; an empty tail with PSG_GAP_UNINITIALIZED leaves an all-zero gap array"""
+    import ctypes as C
+    from psascan_amd._lib import StreamStatsC
+    t = make_text("sig12", 5000, 4)
+    bwt, i0, gt_in, init = _stream_case(t, 100, 2100, 2100, 5000)
+    m = 2000
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    d_gap = A.upload(np.full(m + 1, 0xABCD1234, np.uint32))
+    fin, st = C.c_int64(0), StreamStatsC()
+    rc = gpu_lib.psg_stream_gap_ex(r.h, i0, int(t[2099]), d_text.at(2100), 2900, 0, d_gtin.ptr, init, d_gap.ptr, None, 0, 6, C.byref(fin), C.byref(st))
+    assert rc != 0 and b"flag" in gpu_lib.psg_last_error()
+    rc = gpu_lib.psg_stream_gap_ex(r.h, i0, int(t[2099]), d_text.at(2100), 0, 0, d_gtin.ptr, 7, d_gap.ptr, None, 0, 1, C.byref(fin), C.byref(st))
+    assert rc == 0 and fin.value == 7
+    assert not A.download(d_gap, np.uint32, m + 1).any()
+
+
 def test_stream_gap_overflow_checking_mode(A, monkeypatch):
     """the kernel variant used for tails of >= 2^32 suffixes (returning atomics + overflow flag)"""
     monkeypatch.setenv("PSG_GAP_MODE", "ovf")
