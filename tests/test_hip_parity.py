@@ -266,6 +266,29 @@ def test_gap_hist_from_log(A, gpu_lib, m, nlog, skew):
     assert np.array_equal(A.download(d_gap, np.uint32, m + 1), want)
 
 
+W = 16384   # counters per histogram window (gap_hist.hip: WSIZE)
+
+
+@pytest.mark.parametrize("nwin_m1", [511, 512, 513, 1023, 1024, 1025, 1533, 1534, 1535, 2556, 2557, 4000])
+@pytest.mark.parametrize("tweak", [-1, 0, 5])
+def test_gap_hist_window_geometry(A, gpu_lib, nwin_m1, tweak):
+    """window counts around the points where the partition changes shape: one level up to 512 windows; above,
+    511 level-1 bins of 2^k windows plus a top bin that takes the remainder (k grows at 511*2^k + 512)."""
+    from psascan_amd._lib import check
+    m = nwin_m1 * W + tweak
+    nlog = 400_000
+    rng = np.random.default_rng(m)
+    v = rng.integers(0, m + 1, nlog).astype(np.uint32)
+    v[:2000] = m                      # the last counter, owned by the top bin
+    v[2000:4000] = 0
+    v[rng.integers(0, nlog, nlog // 64)] = 0xFFFFFFFF
+    d_log = A.upload(v)
+    d_gap = A.upload(np.full(m + 1, 1, np.uint32))
+    check(gpu_lib.psgx_gap_hist(d_log.ptr, nlog, m, d_gap.ptr))
+    want = np.bincount(v[v != 0xFFFFFFFF], minlength=m + 1).astype(np.uint32) + 1
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1), want)
+
+
 @pytest.mark.parametrize("kind,nparts", [("sig4z", 3), ("rand255", 4), ("alla", 2)])
 def test_multi_gpu_building_blocks(A, kind, nparts):
     """stream_gap_log over tail sub-ranges -> log_partition -> (exchange emulated on one device)
