@@ -253,7 +253,7 @@ __global__ __launch_bounds__(PSG_WG) void merge_bwt_apply_kernel(const u8 *L, co
                                                                    u32 left_last, const u32 *bv, const u64 *tile_pref, u8 *out,
                                                                    i64 *block_i0) {
   __shared__ u32 scratch[8];
-  __shared__ u8 sL[TILE_B], sR[TILE_B];
+  __shared__ __attribute__((aligned(4))) u8 sL[TILE_B + 8], sR[TILE_B + 8];   // + the bytes in front of an unaligned start
   __shared__ __attribute__((aligned(4))) u8 sO[TILE_B];
   i64 block = ml + mr, nwords = (block + 31) >> 5;
   i64 k0 = (i64)blockIdx.x * TILE_B;
@@ -265,8 +265,14 @@ __global__ __launch_bounds__(PSG_WG) void merge_bwt_apply_kernel(const u8 *L, co
   u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, nr);
   i64 r0 = (i64)tile_pref[blockIdx.x], l0 = k0 - r0;
   int nl = nvalid - (int)nr;
-  for (int k = threadIdx.x; k < nl; k += PSG_WG) sL[k] = L[l0 + k];
-  for (int k = threadIdx.x; k < (int)nr; k += PSG_WG) sR[k] = R[r0 + k];
+  // both source ranges are staged with aligned 4-byte loads (a byte per lane is a quarter of the bandwidth):
+  // the staged copy starts at the 4-byte boundary below the range, offL / offR bytes in front of it
+  const int offL = (int)((uintptr_t)(L + l0) & 3), offR = (int)((uintptr_t)(R + r0) & 3);
+  {
+    const u32 *pL = (const u32 *)(L + l0 - offL), *pR = (const u32 *)(R + r0 - offR);
+    for (int k = threadIdx.x; k * 4 < nl + offL; k += PSG_WG) ((u32 *)sL)[k] = pL[k];
+    for (int k = threadIdx.x; k * 4 < (int)nr + offR; k += PSG_WG) ((u32 *)sR)[k] = pR[k];
+  }
   __syncthreads();
   int z = e0 - (int)o;
   for (int q = 0; q < n; ++q) {
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(PSG_WG) void merge_bwt_apply_kernel(const u8 *L, co
     u8 v;
     if (bit) {
       int ri = (int)o + below;
-      v = (r0 + ri == right_i0) ? (u8)left_last : sR[ri];       // bwt_merge.hpp:128
+      v = (r0 + ri == right_i0) ? (u8)left_last : sR[offR + ri];       // bwt_merge.hpp:128
     } else {
       int li = z + q - below;
-      v = sL[li];
+      v = sL[offL + li];
       if (l0 + li == left_i0) *block_i0 = k0 + e0 + q;           // bwt_merge.hpp:133
     }
     sO[e0 + q] = v;
