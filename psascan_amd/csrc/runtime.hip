@@ -31,9 +31,18 @@ static std::mutex g_pool_mu;
 static std::multimap<size_t, void *> g_pool_free;      // size -> block
 static std::unordered_map<void *, size_t> g_pool_live;  // block -> size
 
+// size classes: 4 KiB granules below 1 MiB; above, the classes 2^k and 1.5 * 2^k (waste <= 33 %).  A hipMalloc of
+// several GiB costs ~25-30 ms per GiB, so the multi-GiB temporaries of a run (rank logs, partition buffers, gap
+// arrays, sorter keys) must find a cached block: with few classes and exact-class reuse every purpose meets its
+// own blocks again in the next pass instead of having them taken by a slightly smaller request.
 static size_t pool_round(size_t b) {
-  size_t g = b >= (1u << 20) ? (size_t)(2u << 20) : (size_t)4096;
-  return (b + g - 1) / g * g;
+  if (b < ((size_t)1 << 20)) return (b + 4095) / 4096 * 4096;
+  size_t c = (size_t)1 << 20;
+  while (c < b) {
+    if (c + c / 2 >= b) return c + c / 2;
+    c <<= 1;
+  }
+  return c;
 }
 
 hipError_t pool_alloc(void **p, size_t bytes) {
@@ -41,7 +50,7 @@ hipError_t pool_alloc(void **p, size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_pool_free.lower_bound(need);
-    if (it != g_pool_free.end() && it->first <= need + need / 4) {
+    if (it != g_pool_free.end() && it->first == need) {
       *p = it->second;
       g_pool_live[*p] = it->first;
       g_pool_free.erase(it);

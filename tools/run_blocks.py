@@ -20,7 +20,7 @@ print(f"n={n} blocks of {blk} MiB: wall {wall:.2f} s, sampled pairs out of order
 tot_stream = 0.0
 suff = 0
 for kind, b, e, st in stats:
-    T = st.n_chains * st.chain_len
+    T = (e - b) - (e - b + 1) // 2 if kind == "A" else n - e      # pass A: right half through left; pass B: whole tail
     print(f"  pass {kind} block [{b},{e}): ~{T / 2**20:.0f} Mi suffixes, total {st.total_ms:.1f} ms (kernel {st.kernel_ms:.1f}, hist {st.hist_ms:.1f}), chains {st.n_chains} x {st.chain_len}, rounds {st.rounds}, unresolved {st.unresolved}")
     tot_stream += st.total_ms
     suff += T

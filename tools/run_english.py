@@ -21,6 +21,6 @@ print(f"whole schedule {time.time() - t0:.1f} s (host SA-IS sorter, single threa
 bad, s = extras.check_sa5(d_text, n, d_out, n, samples=1 << 20, seed=9)
 print("sampled pairs out of order", bad, "permutation sum ok", s == (n * (n - 1) // 2) % (1 << 64))
 for kind, b, e, st in stats:
-    T = st.n_chains * st.chain_len
+    T = (e - b) - (e - b + 1) // 2 if kind == "A" else n - e
     print(f"  pass {kind} block [{b},{e}): ~{T / 2**20:.0f} Mi suffixes, total {st.total_ms:.1f} ms (kernel {st.kernel_ms:.1f} = {T / max(st.kernel_ms, 1e-9) / 1e6:.1f} G suffixes/s, hist {st.hist_ms:.1f}), "
           f"warm-up {st.warmup_steps}, unresolved {st.unresolved}, rounds {st.rounds}")
