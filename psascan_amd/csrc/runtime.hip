@@ -26,26 +26,88 @@ StreamScope::StreamScope(hipStream_t s) : prev(g_override) { g_override = s; }
 StreamScope::~StreamScope() { g_override = prev; }
 void note_kernel_ms(double ms) { g_last_ms = ms; }
 
-// ---- caching allocator ------------------------------------------------------------------
+// ---- device memory: arena for large blocks, size-class cache for small ones -----------------
+// A hipMalloc of several GiB costs ~25-30 ms per GiB (0.9 s for a 34 GiB rank structure), and the multi-GiB
+// temporaries of a run (rank logs, partition buffers, gap arrays, sorter keys) come in sizes that change
+// from pass to pass.  A cache of whole blocks either misses (exact sizes) or lets one purpose take another's
+// block (tolerant sizes); both showed up as 100-500 ms stalls in multi-block runs.  So: blocks of >= 1 MiB
+// are carved out of a few large segments (best fit, split, coalesce on free; 2 MiB granules) -- after the
+// first passes no request reaches the driver.  Reuse is immediate: everything the library enqueues goes to one
+// stream (or is waited for before its buffers are released), so a block freed by the host is not in use.
 static std::mutex g_pool_mu;
-static std::multimap<size_t, void *> g_pool_free;      // size -> block
-static std::unordered_map<void *, size_t> g_pool_live;  // block -> size
+static std::multimap<size_t, void *> g_pool_free;      // small blocks: size -> block
+static std::unordered_map<void *, size_t> g_pool_live;  // small blocks: block -> size
 
-// size classes: 4 KiB granules below 1 MiB; above, the classes 2^k and 1.5 * 2^k (waste <= 33 %).  A hipMalloc of
-// several GiB costs ~25-30 ms per GiB, so the multi-GiB temporaries of a run (rank logs, partition buffers, gap
-// arrays, sorter keys) must find a cached block: with few classes and exact-class reuse every purpose meets its
-// own blocks again in the next pass instead of having them taken by a slightly smaller request.
-static size_t pool_round(size_t b) {
-  if (b < ((size_t)1 << 20)) return (b + 4095) / 4096 * 4096;
-  size_t c = (size_t)1 << 20;
-  while (c < b) {
-    if (c + c / 2 >= b) return c + c / 2;
-    c <<= 1;
+struct ArenaSeg {
+  char *base = nullptr;
+  size_t size = 0, used = 0;
+  std::map<size_t, size_t> free;   // offset -> length, disjoint, never adjacent
+};
+static std::vector<ArenaSeg> g_segs;
+static std::unordered_map<void *, std::pair<int, size_t>> g_big_live;   // block -> (segment, length)
+static const size_t BIG = (size_t)1 << 20, GRAN = (size_t)2 << 20, SEG_MAX = (size_t)8 << 30;
+
+static size_t pool_round(size_t b) { return (b + 4095) / 4096 * 4096; }
+
+static void *arena_carve(size_t need) {   // best fit over all segments; g_pool_mu held
+  int bs = -1;
+  size_t boff = 0, blen = ~(size_t)0;
+  for (int k = 0; k < (int)g_segs.size(); ++k)
+    for (auto &f : g_segs[k].free)
+      if (f.second >= need && f.second < blen) { bs = k; boff = f.first; blen = f.second; }
+  if (bs < 0) return nullptr;
+  ArenaSeg &S = g_segs[(size_t)bs];
+  S.free.erase(boff);
+  if (blen > need) S.free[boff + need] = blen - need;
+  S.used += need;
+  void *p = S.base + boff;
+  g_big_live[p] = {bs, need};
+  return p;
+}
+
+static void arena_release_empty() {   // give wholly free segments back to the driver; g_pool_mu NOT held
+  std::vector<void *> bases;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &S : g_segs)
+      if (S.base && S.used == 0) { bases.push_back(S.base); S.base = nullptr; S.size = 0; S.free.clear(); }
   }
-  return c;
+  if (!bases.empty()) {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (g_side) (void)hipStreamSynchronize(g_side);
+  }
+  for (void *b : bases) (void)hipFree(b);
 }
 
 hipError_t pool_alloc(void **p, size_t bytes) {
+  if (bytes >= BIG) {
+    const size_t need = (bytes + GRAN - 1) / GRAN * GRAN;
+    size_t total = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if ((*p = arena_carve(need)) != nullptr) return hipSuccess;
+      for (auto &S : g_segs) total += S.size;
+    }
+    // new segment: at least the request, otherwise doubling the arena up to 8 GiB steps
+    size_t seg = std::max(need, std::min(SEG_MAX, std::max((size_t)64 << 20, total)));
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, seg);
+    if (e != hipSuccess && seg > need) { (void)hipGetLastError(); seg = need; e = hipMalloc(&base, seg); }
+    if (e != hipSuccess) {   // give everything unused back and retry once
+      (void)hipGetLastError();
+      pool_trim();
+      e = hipMalloc(&base, seg);
+    }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int slot = -1;
+    for (int k = 0; k < (int)g_segs.size(); ++k) if (!g_segs[(size_t)k].base) { slot = k; break; }
+    if (slot < 0) { g_segs.emplace_back(); slot = (int)g_segs.size() - 1; }
+    ArenaSeg &S = g_segs[(size_t)slot];
+    S.base = (char *)base; S.size = seg; S.used = 0; S.free.clear(); S.free[0] = seg;
+    *p = arena_carve(need);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+  }
   size_t need = pool_round(bytes);
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -70,6 +132,21 @@ hipError_t pool_alloc(void **p, size_t bytes) {
 void pool_free(void *p) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto bg = g_big_live.find(p);
+  if (bg != g_big_live.end()) {
+    ArenaSeg &S = g_segs[(size_t)bg->second.first];
+    size_t off = (size_t)((char *)p - S.base), len = bg->second.second;
+    g_big_live.erase(bg);
+    S.used -= len;
+    auto nx = S.free.lower_bound(off);
+    if (nx != S.free.end() && off + len == nx->first) { len += nx->second; nx = S.free.erase(nx); }   // merge with the next range
+    if (nx != S.free.begin()) {
+      auto pv = std::prev(nx);
+      if (pv->first + pv->second == off) { off = pv->first; len += pv->second; S.free.erase(pv); }    // and with the previous one
+    }
+    S.free[off] = len;
+    return;
+  }
   auto it = g_pool_live.find(p);
   if (it == g_pool_live.end()) { (void)hipFree(p); return; }
   g_pool_free.emplace(it->second, p);
@@ -80,6 +157,7 @@ size_t pool_cached_bytes() {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   size_t t = 0;
   for (auto &kv : g_pool_free) t += kv.first;
+  for (auto &S : g_segs) t += S.size - S.used;
   return t;
 }
 
@@ -92,6 +170,7 @@ void pool_trim() {
   }
   if (!blocks.empty() && g_stream) { (void)hipStreamSynchronize(g_stream); if (g_side) (void)hipStreamSynchronize(g_side); }
   for (void *b : blocks) (void)hipFree(b);
+  arena_release_empty();
 }
 
 // ---- event recycling -----------------------------------------------------------------------
