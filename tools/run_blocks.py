@@ -1,5 +1,5 @@
 """Multi-block run on one GPU with the device-side sorter (random bytes): per-pass statistics.
-    python tools/run_blocks.py [text_MiB] [block_MiB]"""
+    python tools/run_blocks.py [text_MiB] [block_MiB] [bytes|dna]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -7,7 +7,8 @@ from psascan_amd import api, extras, pipeline
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 blk = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n = (mib << 20) + 12345
-d_text = extras.gen_text(n, 0, 0, seed=7)
+mode = extras.MODE_DNA if len(sys.argv) > 3 and sys.argv[3] == "dna" else extras.MODE_BYTES255
+d_text = extras.gen_text(n, mode, 0, seed=7)
 text = api.download(d_text, np.uint8, n)
 sorter = extras.DeviceSorter(d_text, n)
 stats = []
