@@ -25,4 +25,10 @@ def sig4_with_zero():
     return np.random.default_rng(3).integers(0, 4, 1 << 16, dtype=np.uint8)
 
 
+def rand64m():
+    return np.random.default_rng(7).integers(0, 255, 64 << 20, dtype=np.uint8)
+
+
+# the fixtures every suite iterates over; LARGE ones are only run end to end on the GPU (tests/test_host.py)
+LARGE_GENERATORS = {"rand64m": rand64m}
 GENERATORS = {"rand1m": rand1m, "per3": per3, "alla": alla, "fib": fib, "sig4_with_zero": sig4_with_zero}

@@ -165,6 +165,25 @@ def test_cli_end_to_end_vs_reference_hashes(tmp_path, name):
 
 
 @pytest.mark.gpu
+def test_cli_64mib_vs_reference_hash(tmp_path):
+    """64 MiB of random bytes in four 16 MiB blocks (pass B tails of 16/32/48 MiB: rank-log mode, chunk-free):
+    the .sa5 must hash to what the reference's construct_sa wrote for the same input and -m."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))["rand64m"]
+    f = tmp_path / "rand64m.bin"
+    f.write_bytes(bytes(gin.LARGE_GENERATORS["rand64m"]()))
+    env = dict(os.environ, OMP_NUM_THREADS=str(g["threads"]))
+    r = subprocess.run([CLI, "-m", str(g["ram_use"]), "-v", str(f)], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Max block size = {g['max_block_size']}" in r.stderr
+    h = hashlib.sha256()
+    with open(tmp_path / "rand64m.bin.sa5", "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 24), b""):
+            h.update(chunk)
+    assert os.path.getsize(tmp_path / "rand64m.bin.sa5") == 5 * g["n"]
+    assert h.hexdigest() == g["sa5_sha256"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,block", [(1, 4), (2, 4), (5, 2), (1000, 64), (4097, 1000), (30000, 30000), (30000, 7000)])
 def test_cli_small_shapes(tmp_path, n, block):
     rng = np.random.default_rng(n + block)
