@@ -14,7 +14,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -157,6 +161,63 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   };
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
+
+  // ---- look-ahead sorter: all half-blocks on all host cores, right to left (the order the schedule needs them).
+  // The comparisons that run past a half-block's end are decided by reading on in the text, which is in host
+  // memory, instead of by the gt bits of the blocks to the right (initial_partial_sufsort.hpp:61-80) -- so a
+  // half-block depends on nothing.  A half-block whose comparisons run longer than LOOKAHEAD_CAP symbols is
+  // left to the sequential schedule below (gt bits from the streaming passes, as in the reference).
+  const int64_t LOOKAHEAD_CAP = 1 << 16;
+  struct Pre { std::unique_ptr<HalfBlock> hb; bool done = false, failed = false; double seconds = 0; };
+  std::vector<Pre> pre((size_t)(2 * n_blocks));           // [2*bid] = left half, [2*bid+1] = right half
+  std::mutex pre_mu;
+  std::condition_variable pre_cv;
+  std::atomic<int64_t> next_task{0};
+  std::vector<int64_t> task_order;                        // right half of the last block first
+  for (int64_t bid = n_blocks - 1; bid >= 0; --bid) { task_order.push_back(2 * bid + 1); task_order.push_back(2 * bid); }
+  auto half_range = [&](int64_t id, int64_t &hb_beg, int64_t &hb_end) {
+    const int64_t bid = id / 2, b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
+    const bool last = e == n;
+    const int64_t ls = last ? std::min<int64_t>(bs, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, bs / 2);
+    if (id & 1) { hb_beg = b + ls; hb_end = e; } else { hb_beg = b; hb_end = b + ls; }
+  };
+  const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD");
+  std::vector<std::thread> workers;
+  if (lookahead) {
+    const long nthreads = std::min<long>(max_threads, (long)task_order.size());
+    for (long t = 0; t < nthreads; ++t)
+      workers.emplace_back([&]() {
+        for (;;) {
+          const int64_t k = next_task.fetch_add(1);
+          if (k >= (int64_t)task_order.size()) return;
+          const int64_t id = task_order[(size_t)k];
+          int64_t hb_beg, hb_end;
+          half_range(id, hb_beg, hb_end);
+          std::unique_ptr<HalfBlock> h;
+          bool failed = false;
+          const double t0 = wclock();
+          if (hb_end > hb_beg) {
+            try {
+              h.reset(new HalfBlock());
+              psa_host::sort_halfblock(text.data(), n, hb_beg, hb_end, psa_host::gt_tail_direct(text.data(), n, hb_end, LOOKAHEAD_CAP), *h, LOOKAHEAD_CAP);
+            } catch (const psa_host::GtCapExceeded &) { h.reset(); failed = true; }
+              catch (...) { h.reset(); failed = true; }       // e.g. byte 255: reported by the sequential path
+          }
+          std::lock_guard<std::mutex> lk(pre_mu);
+          pre[(size_t)id].hb = std::move(h); pre[(size_t)id].failed = failed; pre[(size_t)id].seconds = wclock() - t0; pre[(size_t)id].done = true;
+          pre_cv.notify_all();
+        }
+      });
+  }
+  struct Joiner { std::vector<std::thread> &w; ~Joiner() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{workers};
+  // the pre-sorted half-block `id`, or null when there is none (look-ahead off, or it gave up)
+  auto take_pre = [&](int64_t id) -> std::unique_ptr<HalfBlock> {
+    if (!lookahead) return nullptr;
+    std::unique_lock<std::mutex> lk(pre_mu);
+    pre_cv.wait(lk, [&] { return pre[(size_t)id].done; });
+    return std::move(pre[(size_t)id].hb);
+  };
+
   for (int64_t bid = n_blocks - 1; bid >= 0; --bid) {   // partial_sufsort.hpp:568
     const int64_t b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
     const bool last_block = e == n;
@@ -170,8 +231,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     HalfBlock R, L;
     double t0 = wclock();
     if (rs > 0) {
-      psa_host::sort_halfblock(text.data(), n, mid, e, gt_tail_e, R);
-      log_phase("host sufsort (right half)", t0, rs);
+      if (auto p = take_pre(2 * bid + 1)) { R = std::move(*p); log_phase("host sufsort (right half, sorted ahead; waited)", t0, rs); }
+      else {
+        psa_host::sort_halfblock(text.data(), n, mid, e, gt_tail_e, R);
+        log_phase("host sufsort (right half)", t0, rs);
+      }
     }
     auto gt_tail_mid = [&](int64_t v) {  // position mid+v in (mid, e]: right half's gt_begin, u = e - j
       if (rs == 0) return gt_tail_e(v);
@@ -179,8 +243,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       return (bool)((R.gt_begin[(size_t)(u >> 5)] >> (u & 31)) & 1u);
     };
     t0 = wclock();
-    psa_host::sort_halfblock(text.data(), n, b, mid, gt_tail_mid, L);
-    log_phase("host sufsort (left half)", t0, ls);
+    if (auto p = take_pre(2 * bid)) { L = std::move(*p); log_phase("host sufsort (left half, sorted ahead; waited)", t0, ls); }
+    else {
+      psa_host::sort_halfblock(text.data(), n, b, mid, gt_tail_mid, L);
+      log_phase("host sufsort (left half)", t0, ls);
+    }
     Dev d_lgt = upload(L.gt_begin.data(), 4 * (int64_t)L.gt_begin.size());
     DevHalfBlock hbL = up_hb(L);
     if (rs == 0) {

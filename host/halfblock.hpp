@@ -32,11 +32,32 @@ struct HalfBlock {
 // gt_tail(v), v >= 1: [text[end+v..n) > text[end..n)]   (only asked for end+v < n)
 typedef std::function<bool(int64_t)> GtTail;
 
-// [text[s..n) > text[e..n)] for beg <= s < e = end, using text up to `end` and gt_tail beyond
-static inline bool gt_wrt_end(const uint8_t *text, int64_t n, int64_t s, int64_t e, const GtTail &gt_tail) {
+// Thrown by the look-ahead sorter when a comparison runs longer than its cap: that half-block is then sorted in
+// the sequential schedule, with the gt bits the streaming passes produce (highly repetitive text).
+struct GtCapExceeded {};
+
+// gt_tail by direct comparison in the text (the whole text is in host memory): needs nothing from other blocks,
+// so half-blocks can be sorted ahead of the block schedule, on all host cores.  Bounded: throws GtCapExceeded
+// after `cap` equal symbols.
+static inline GtTail gt_tail_direct(const uint8_t *text, int64_t n, int64_t end, int64_t cap) {
+  return [=](int64_t v) {
+    const int64_t a = end + v, b = end;     // [text[a..n) > text[b..n)], a > b
+    for (int64_t k = 0;; ++k) {
+      if (a + k >= n) return false;         // text[a..n) is a proper prefix of text[b..n)
+      if (k >= cap) throw GtCapExceeded();
+      const uint8_t x = text[a + k], y = text[b + k];
+      if (x != y) return x > y;
+    }
+  };
+}
+
+// [text[s..n) > text[e..n)] for beg <= s < e = end, using text up to `end` and gt_tail beyond.
+// cap > 0: give up (GtCapExceeded) after that many equal symbols.
+static inline bool gt_wrt_end(const uint8_t *text, int64_t n, int64_t s, int64_t e, const GtTail &gt_tail, int64_t cap = 0) {
   int64_t lim = e - s;  // symbols of the s-suffix that lie before e
   for (int64_t k = 0; k < lim; ++k) {
     if (e + k >= n) return true;  // text[e..n) is a proper prefix of text[s..n)
+    if (cap > 0 && k >= cap) throw GtCapExceeded();
     uint8_t a = text[s + k], b = text[e + k];
     if (a != b) return a > b;
   }
@@ -46,7 +67,7 @@ static inline bool gt_wrt_end(const uint8_t *text, int64_t n, int64_t s, int64_t
 }
 
 static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, int64_t end, const GtTail &gt_tail,
-                                  HalfBlock &out) {
+                                  HalfBlock &out, int64_t cap = 0) {
   const int64_t m = end - beg;
   out.beg = beg; out.size = m;
   std::vector<uint8_t> blk(text + beg, text + end);
@@ -54,11 +75,11 @@ static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, i
   uint8_t last = blk[(size_t)m - 1];
   bool gt_of_beg = false;  // [text[beg..) > text[end..)]
   if (end < n) {
-    gt_of_beg = gt_wrt_end(text, n, beg, end, gt_tail);
+    gt_of_beg = gt_wrt_end(text, n, beg, end, gt_tail, cap);
     renamed = true;
     for (int64_t i = 0; i + 1 < m; ++i) {
       uint8_t c = blk[(size_t)i];
-      if (c > last || (c == last && gt_wrt_end(text, n, beg + i + 1, end, gt_tail))) {
+      if (c > last || (c == last && gt_wrt_end(text, n, beg + i + 1, end, gt_tail, cap))) {
         if (c == 255) throw std::runtime_error("the input contains byte 255");
         blk[(size_t)i] = c + 1;
       }
