@@ -42,6 +42,32 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PMC_TRAFFIC_B_PER_SUFFIX = {8.3: 71.5, 16.0: 71.4}
 
 
+def end_to_end_cli(sample_mib, log):
+    """The whole construct_sa program (host/construct_sa: read the file, host SA-IS of the half-blocks on the host
+    threads, the device passes, merge, write the .sa5) on a bounded sample, as a child process.  Reported next to
+    the hot-path metric; it is bound by the host sorter, not by the GPU."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    cli = os.path.join(ROOT, "host", "construct_sa")
+    if not os.path.exists(cli):
+        return None
+    threads = min(16, os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "sample.bin")
+        np.random.default_rng(11).integers(0, 255, sample_mib << 20, dtype=np.uint8).tofile(f)
+        t0 = time.time()
+        r = subprocess.run([cli, "-m", "8G", "--block-size", str(16 << 20), f], capture_output=True, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=600)
+        wall = time.time() - t0
+        ok = r.returncode == 0 and os.path.getsize(f + ".sa5") == 5 * (sample_mib << 20)
+    if not ok:
+        log("construct_sa failed:", r.stderr[-300:])
+        return {"value": None, "unit": "MB/s", "sample": "failed"}
+    return {"value": (sample_mib << 20) / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2),
+            "sample": f"{sample_mib} MiB uniform bytes 0..254 from a file, 16 MiB blocks, .sa5 written to a file; wall time of the child process"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +361,10 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(api, extras, args.cpu_sample_mib, log)
             except Exception as e:  # the baseline must not take the bench down
                 res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
+            try:
+                res["end_to_end_cli"] = end_to_end_cli(256, log)
+            except Exception as e:
+                res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
