@@ -202,6 +202,36 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+def test_device_allocator_arena(A, gpu_lib):
+    """psg_malloc/psg_free go through the arena of runtime.hip (best fit, split, coalesce for blocks >= 1 MiB,
+    size classes below): live blocks never overlap, whatever the order of frees and the mix of sizes."""
+    rng = np.random.default_rng(42)
+    live = {}
+
+    def alloc(tag):
+        nbytes = int(rng.choice([4096, 70_000, (1 << 20) + 8, 3 << 20, (7 << 20) + 123, 33 << 20, 130 << 20]))
+        b = A.DeviceBuffer(nbytes)
+        assert gpu_lib.psg_memset(b.ptr, tag & 255, nbytes) == 0
+        live[tag] = (b, nbytes)
+
+    tag = 0
+    for _ in range(24):
+        alloc(tag); tag += 1
+    for rnd in range(6):
+        for t in list(live)[:: 2 + rnd % 2]:            # free every 2nd / 3rd block
+            live.pop(t)[0].free()
+        for _ in range(10):
+            alloc(tag); tag += 1
+        A.sync()
+        for t, (b, nbytes) in live.items():             # every live block still holds its own byte everywhere sampled
+            for off in (0, nbytes // 2, nbytes - 1):
+                assert int(A.download(b, np.uint8, 1, off)[0]) == (t & 255), (t, off)
+    spans = sorted((b.ptr, b.ptr + nbytes) for b, nbytes in live.values())
+    assert all(spans[k][1] <= spans[k + 1][0] for k in range(len(spans) - 1))
+    for b, _ in live.values():
+        b.free()
+
+
 def test_stream_gap_ex_contract(A, gpu_lib):
     """psg_stream_gap_ex: unknown flags are rejected; an empty tail with PSG_GAP_UNINITIALIZED leaves an all-zero gap array"""
     import ctypes as C
