@@ -199,7 +199,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
           if (hb_end > hb_beg) {
             try {
               h.reset(new HalfBlock());
-              psa_host::sort_halfblock(text.data(), n, hb_beg, hb_end, psa_host::gt_tail_direct(text.data(), n, hb_end, LOOKAHEAD_CAP), *h, LOOKAHEAD_CAP);
+              if (!psa_host::sort_halfblock_radix(text.data(), n, hb_beg, hb_end, *h, LOOKAHEAD_CAP)) {   // text with repeats: SA-IS
+                h.reset(new HalfBlock());
+                psa_host::sort_halfblock(text.data(), n, hb_beg, hb_end, psa_host::gt_tail_direct(text.data(), n, hb_end, LOOKAHEAD_CAP), *h, LOOKAHEAD_CAP);
+              }
             } catch (const psa_host::GtCapExceeded &) { h.reset(); failed = true; }
               catch (...) { h.reset(); failed = true; }       // e.g. byte 255: reported by the sequential path
           }

@@ -28,6 +28,28 @@ int psh_sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, int64_t end,
   } catch (const std::exception &) { return -1; }
 }
 
+// look-ahead sorters of construct_sa: order by reading on in the text past `end` (no gt bits needed).
+// method 0: SA-IS + rename with direct comparisons; 1: prefix-key radix sort.  Returns 1 when the method gives up
+// (comparisons longer than cap / large groups of equal prefixes), -1 on bad input.
+int psh_sort_halfblock_ahead(const uint8_t *text, int64_t n, int64_t beg, int64_t end, int method, int64_t cap,
+                             uint32_t *psa_lo, uint8_t *bwt, int64_t *i0, uint32_t *gt_begin) {
+  try {
+    psa_host::HalfBlock hb;
+    if (method == 1) {
+      if (!psa_host::sort_halfblock_radix(text, n, beg, end, hb, cap)) return 1;
+    } else {
+      try { psa_host::sort_halfblock(text, n, beg, end, psa_host::gt_tail_direct(text, n, end, cap), hb, cap); }
+      catch (const psa_host::GtCapExceeded &) { return 1; }
+    }
+    if (!hb.psa_hi.empty()) return -2;
+    memcpy(psa_lo, hb.psa_lo.data(), 4 * (size_t)hb.size);
+    memcpy(bwt, hb.bwt.data(), (size_t)hb.size);
+    memcpy(gt_begin, hb.gt_begin.data(), 4 * (size_t)((hb.size + 31) / 32));
+    *i0 = hb.i0;
+    return 0;
+  } catch (const std::exception &) { return -1; }
+}
+
 int64_t psh_rank_by_search(const uint8_t *text, int64_t n, int64_t beg, int64_t size, const uint32_t *psa_lo, int64_t p) {
   psa_host::HalfBlock hb;
   hb.beg = beg; hb.size = size;

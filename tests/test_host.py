@@ -29,6 +29,9 @@ def H():
     L.psh_sort_halfblock.argtypes = [orc.u8p, C.c_int64, C.c_int64, C.c_int64, orc.u8p,
                                      np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), orc.u8p, C.POINTER(C.c_int64),
                                      np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
+    L.psh_sort_halfblock_ahead.argtypes = [orc.u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64,
+                                           np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), orc.u8p, C.POINTER(C.c_int64),
+                                           np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
     L.psh_rank_by_search.argtypes = [orc.u8p, C.c_int64, C.c_int64, C.c_int64,
                                      np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int64]
     L.psh_rank_by_search.restype = C.c_int64
@@ -88,6 +91,45 @@ def test_sort_halfblock_vs_definition(H, name):
         for p in (e, min(n, e + 5), n):
             want = int((isa[b:e] < (isa[p] if p < n else -1)).sum())
             assert H.psh_rank_by_search(t, n, b, m, psa, p) == want
+
+
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("name", list(texts().keys()) + ["rand254-long", "english"])
+def test_lookahead_sorters_vs_definition(H, name, method):
+    """construct_sa's look-ahead sorters (no gt bits: comparisons past the half-block's end read on in the text):
+    SA-IS with direct comparisons (0) and the prefix-key radix sorter (1).  Either the definition's result, or an
+    explicit 'gave up' (1) on periodic text -- never a wrong order."""
+    if name == "rand254-long":
+        t = np.random.default_rng(5).integers(0, 254, 200_000, dtype=np.uint8)
+    elif name == "english":
+        words = [b"the", b"of", b"and", b"suffix", b"array", b"block", b"stream", b"gap", b"merge", b"a"]
+        rng = np.random.default_rng(9)
+        t = np.frombuffer(b" ".join(words[i] for i in rng.integers(0, len(words), 12000)), np.uint8).copy()
+    else:
+        t = texts()[name]
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    gave_up = 0
+    for (b, e) in [(n // 5, n // 2), (0, n // 3), (n // 2, n), (n - 7, n), (n // 2, n // 2 + 2), (0, n)]:
+        m = e - b
+        psa = np.zeros(m, np.uint32)
+        bwt = np.zeros(m, np.uint8)
+        gt = np.zeros((m + 31) // 32 + 1, np.uint32)
+        i0 = C.c_int64(-1)
+        rc = H.psh_sort_halfblock_ahead(t, n, b, e, method, 64, psa, bwt, C.byref(i0), gt)
+        assert rc in (0, 1)
+        if rc == 1:
+            gave_up += 1
+            continue
+        wpsa, wbwt, wi0, wgt = orc.partial_sa(t, sa, isa, b, e)
+        assert np.array_equal(psa.astype(np.int64), wpsa), (name, b, e)
+        assert np.array_equal(bwt, wbwt) and i0.value == wi0
+        assert np.array_equal(orc.bits(gt.view(np.uint8), m), orc.bits(wgt, m)), (name, b, e)
+    if name in ("rand254", "rand254-long", "sig4z", "english"):
+        assert gave_up == 0            # ordinary text is sorted ahead
+    if name in ("alla", "zeros", "per3"):
+        assert gave_up > 0             # periodic text is left to the sequential schedule
 
 
 def test_sort_halfblock_rejects_byte_255(H):
