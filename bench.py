@@ -57,7 +57,7 @@ def end_to_end_cli(sample_mib, log):
         f = os.path.join(d, "sample.bin")
         np.random.default_rng(11).integers(0, 255, sample_mib << 20, dtype=np.uint8).tofile(f)
         t0 = time.time()
-        r = subprocess.run([cli, "-m", "8G", "--block-size", str(16 << 20), f], capture_output=True, text=True,
+        r = subprocess.run([cli, "-m", "8G", "--block-size", str(32 << 20), f], capture_output=True, text=True,
                            env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=600)
         wall = time.time() - t0
         ok = r.returncode == 0 and os.path.getsize(f + ".sa5") == 5 * (sample_mib << 20)
@@ -65,7 +65,7 @@ def end_to_end_cli(sample_mib, log):
         log("construct_sa failed:", r.stderr[-300:])
         return {"value": None, "unit": "MB/s", "sample": "failed"}
     return {"value": (sample_mib << 20) / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2),
-            "sample": f"{sample_mib} MiB uniform bytes 0..254 from a file, 16 MiB blocks, .sa5 written to a file; wall time of the child process"}
+            "sample": f"{sample_mib} MiB uniform bytes 0..254 from a file, 32 MiB blocks, .sa5 written to a file; wall time of the child process"}
 
 
 def parse():
@@ -362,7 +362,7 @@ def main():
             except Exception as e:  # the baseline must not take the bench down
                 res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
             try:
-                res["end_to_end_cli"] = end_to_end_cli(256, log)
+                res["end_to_end_cli"] = end_to_end_cli(1024, log)
             except Exception as e:
                 res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
