@@ -182,6 +182,17 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (id & 1) { hb_beg = b + ls; hb_end = e; } else { hb_beg = b; hb_end = b + ls; }
   };
   const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD");
+  // how far the sorters may run ahead of the schedule: a finished half-block holds ~5 bytes per symbol until it
+  // is consumed and a running sort ~25 more, so the window is bounded by a quarter of the physical memory
+  int64_t consumed = 0;            // tasks (in task_order) the schedule has taken; guarded by pre_mu
+  bool stop_workers = false;       // set when the schedule ends (normally or by an exception); guarded by pre_mu
+  int64_t window = 2;
+  {
+    const int64_t half_bytes = std::max<int64_t>(1, (max_block_size + 1) / 2);
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    const int64_t phys = pages > 0 && psz > 0 ? (int64_t)pages * psz : ((int64_t)16 << 30);
+    window = std::max<int64_t>(2, std::min<int64_t>(4 * max_threads, (phys / 4) / (30 * half_bytes)));
+  }
   std::vector<std::thread> workers;
   if (lookahead) {
     const long nthreads = std::min<long>(max_threads, (long)task_order.size());
@@ -190,6 +201,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
         for (;;) {
           const int64_t k = next_task.fetch_add(1);
           if (k >= (int64_t)task_order.size()) return;
+          {
+            std::unique_lock<std::mutex> lk(pre_mu);
+            pre_cv.wait(lk, [&] { return stop_workers || k < consumed + window; });
+            if (stop_workers) return;
+          }
           const int64_t id = task_order[(size_t)k];
           int64_t hb_beg, hb_end;
           half_range(id, hb_beg, hb_end);
@@ -212,12 +228,21 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
         }
       });
   }
-  struct Joiner { std::vector<std::thread> &w; ~Joiner() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{workers};
+  struct Joiner {
+    std::vector<std::thread> &w; std::mutex &mu; std::condition_variable &cv; bool &stop;
+    ~Joiner() {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      for (auto &t : w) if (t.joinable()) t.join();
+    }
+  } joiner{workers, pre_mu, pre_cv, stop_workers};
   // the pre-sorted half-block `id`, or null when there is none (look-ahead off, or it gave up)
   auto take_pre = [&](int64_t id) -> std::unique_ptr<HalfBlock> {
     if (!lookahead) return nullptr;
     std::unique_lock<std::mutex> lk(pre_mu);
     pre_cv.wait(lk, [&] { return pre[(size_t)id].done; });
+    ++consumed;                      // the tasks are taken in task_order, one per call
+    pre_cv.notify_all();
     return std::move(pre[(size_t)id].hb);
   };
 
@@ -233,6 +258,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     auto gt_tail_e = [&](int64_t v) { int64_t idx = n - (e + v); return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u); };
     HalfBlock R, L;
     double t0 = wclock();
+    if (rs == 0 && lookahead) { std::lock_guard<std::mutex> lk(pre_mu); ++consumed; pre_cv.notify_all(); }   // its (empty) right-half task
     if (rs > 0) {
       if (auto p = take_pre(2 * bid + 1)) { R = std::move(*p); log_phase("host sufsort (right half, sorted ahead; waited)", t0, rs); }
       else {
