@@ -361,13 +361,25 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   CK(psg_merge_plan_create(desc.data(), (int)desc.size(), &plan));
   const int64_t slice = 64LL << 20;  // output entries per slice
   Dev d_out(5 * std::min(slice, n) + 16);
-  std::vector<uint8_t> h_out((size_t)(5 * std::min(slice, n)));
-  for (int64_t x = 0; x < n; x += slice) {
+  // two host buffers: slice k is written to the file by a helper thread while slice k+1 is merged and copied back
+  std::vector<uint8_t> h_out[2];
+  h_out[0].resize((size_t)(5 * std::min(slice, n)));
+  if (n > slice) h_out[1].resize((size_t)(5 * slice));
+  std::thread writer;
+  bool write_ok = true;
+  struct WriterJoin { std::thread &t; ~WriterJoin() { if (t.joinable()) t.join(); } } writer_join{writer};
+  int which = 0;
+  for (int64_t x = 0; x < n; x += slice, which ^= 1) {
     int64_t cnt = std::min(slice, n - x);
     CK(psg_merge_run(plan, x, cnt, d_out.as<uint8_t>()));
-    CK(psg_d2h(h_out.data(), d_out.p, 5 * cnt));
-    if (fwrite(h_out.data(), 1, (size_t)(5 * cnt), out) != (size_t)(5 * cnt)) throw std::runtime_error("write failed on " + out_fn);
+    CK(psg_d2h(h_out[which].data(), d_out.p, 5 * cnt));
+    if (writer.joinable()) writer.join();
+    if (!write_ok) throw std::runtime_error("write failed on " + out_fn);
+    const uint8_t *src = h_out[which].data();
+    writer = std::thread([src, cnt, out, &write_ok] { if (fwrite(src, 1, (size_t)(5 * cnt), out) != (size_t)(5 * cnt)) write_ok = false; });
   }
+  if (writer.joinable()) writer.join();
+  if (!write_ok) throw std::runtime_error("write failed on " + out_fn);
   psg_merge_plan_free(plan);
   fclose(out);
   log_phase("merge + write", t0, 5 * n);
