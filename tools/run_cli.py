@@ -15,3 +15,19 @@ with tempfile.TemporaryDirectory() as d:
     print("rc", r.returncode, " ".join(cmd[1:-1]), "threads", thr)
     lines = r.stderr.strip().splitlines()
     print("\n".join(lines[-6:]))
+    # spot check: sampled adjacent entries of the .sa5 must be in suffix order, and the file must have 5n bytes
+    n = mib << 20
+    text = np.memmap(f, np.uint8, "r")
+    assert os.path.getsize(f + ".sa5") == 5 * n
+    sa5 = np.memmap(f + ".sa5", np.uint8, "r")
+    rng = np.random.default_rng(1)
+    bad = 0
+    big = 0
+    for k in rng.integers(0, n - 1, 20000):
+        e = np.array(sa5[5 * k: 5 * k + 10]).astype(np.int64)
+        a = int(e[0] | e[1] << 8 | e[2] << 16 | e[3] << 24 | e[4] << 32)
+        b = int(e[5] | e[6] << 8 | e[7] << 16 | e[8] << 24 | e[9] << 32)
+        big += a >= (1 << 32)
+        if a >= n or b >= n or not bytes(text[a:a + 256]) <= bytes(text[b:b + 256]):
+            bad += 1
+    print(f"sampled adjacent pairs out of order: {bad} of 20000 (positions >= 2^32 among them: {big})")
