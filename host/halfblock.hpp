@@ -11,6 +11,7 @@
 // This is why byte 255 is not allowed in the input (same restriction as the reference,
 // initial_partial_sufsort.hpp:141-146).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
@@ -142,49 +143,19 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   while ((1 << bits) <= sigma) ++bits;
   const int per_key = 64 / bits, used = per_key * bits;
   const uint64_t keep = used == 64 ? ~0ull : ~((1ull << (64 - used)) - 1ull);
-  std::vector<uint64_t> key((size_t)m), key2((size_t)m);
-  std::vector<uint32_t> idx((size_t)m), idx2((size_t)m);
-  int sorted_bits = 64;
-  {
-    uint64_t k = 0;   // symbols i .. i+per_key-1 in the top `used` bits, rolled in from the right
-    for (int64_t i = std::min<int64_t>(n, end + per_key) - 1; i >= beg; --i) {
-      k = (((uint64_t)code[text[i]] << (64 - bits)) | (k >> bits)) & keep;
-      if (i < end) { key[(size_t)(i - beg)] = k; idx[(size_t)(i - beg)] = (uint32_t)(i - beg); }
-    }
-  }
-  {
-    // LSD radix sort, 11-bit digits: 2048 output streams per pass stay within reach of the caches / TLB
-    // (65536 streams cost more per pass than the two passes they save)
-    const int DB = 11;
-    std::vector<uint32_t> cnt((size_t)1 << DB);
-    // only the top `need` key bits are radix-sorted: enough to leave groups of a few suffixes, which the
-    // comparison step below finishes (first on the rest of the key, then in the text)
-    int lg = 0;
-    while (((int64_t)1 << lg) < m) ++lg;
-    const int need = std::min(used, lg + 8);
-    sorted_bits = need;
-    for (int shift = 64 - need; shift < 64; shift += DB) {
-      const uint64_t dmask = ((uint64_t)1 << std::min(DB, 64 - shift)) - 1;
-      std::fill(cnt.begin(), cnt.end(), 0u);
-      for (int64_t i = 0; i < m; ++i) ++cnt[(size_t)((key[(size_t)i] >> shift) & dmask)];
-      uint32_t run = 0;
-      bool one_bucket = false;
-      for (size_t b = 0; b < cnt.size(); ++b) { uint32_t c = cnt[b]; if (c == (uint32_t)m) one_bucket = true; cnt[b] = run; run += c; }
-      if (one_bucket) continue;   // this digit is the same everywhere
-      for (int64_t i = 0; i < m; ++i) {
-        const uint64_t kk = key[(size_t)i];
-        const uint32_t d = cnt[(size_t)((kk >> shift) & dmask)]++;
-        key2[(size_t)d] = kk; idx2[(size_t)d] = idx[(size_t)i];
-      }
-      key.swap(key2); idx.swap(idx2);
-    }
-  }
-  std::vector<uint64_t>().swap(key2);
-  std::vector<uint32_t>().swap(idx2);
-  // groups of equal keys: suffixes that agree on their first per_key symbols
+  // only the top `need` key bits are radix-sorted: enough to leave groups of a few suffixes, which a
+  // comparison step finishes
+  int lg = 0;
+  while (((int64_t)1 << lg) < m) ++lg;
+  // a key bit carries log2(sigma)/bits bits of information (the codes 1..sigma do not fill the 2^bits values)
+  const double info = sigma >= 2 ? std::log2((double)sigma) / bits : 1.0;
+  int need = std::min(used, (int)std::ceil((lg + 8) / info));
+  if (need > 32 && (int)std::ceil((lg + 5) / info) <= 32) need = 32;   // the packed 32-bit path below; groups a little larger
+  std::vector<uint32_t> idx((size_t)m);
   int64_t budget = 64 * m + (1 << 20);   // total symbol comparisons allowed before SA-IS is the better tool
-  auto less = [&](uint32_t a, uint32_t b) {   // text[beg+a ..n) < text[beg+b ..n), known equal on per_key symbols
-    int64_t x = beg + a + per_key, y = beg + b + per_key;
+  // text[beg+a ..n) < text[beg+b ..n) for two suffixes known to agree on their first `known` symbols
+  auto less_from = [&](uint32_t a, uint32_t b, int known) {
+    int64_t x = beg + a + known, y = beg + b + known;
     for (int64_t k = 0;; ++k) {
       if (x + k >= n) return y + k < n || a > b;    // ran off the text: the shorter suffix is smaller
       if (y + k >= n) return false;
@@ -193,25 +164,87 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
       if (p != q) return p < q;
     }
   };
+  const int DB = 11;   // LSD digits: 2048 output streams per pass stay within reach of the caches / TLB
+  std::vector<uint32_t> cnt((size_t)1 << DB);
   try {
-    const int gs = 64 - sorted_bits;   // a group = equal radix-sorted bits
-    std::vector<std::pair<uint64_t, uint32_t>> grp;
-    for (int64_t g0 = 0; g0 < m;) {
-      int64_t g1 = g0 + 1;
-      while (g1 < m && (key[(size_t)g1] >> gs) == (key[(size_t)g0] >> gs)) ++g1;
-      if (g1 - g0 > 1) {
-        if (g1 - g0 > (1 << 16)) return false;
-        grp.clear();
-        for (int64_t k = g0; k < g1; ++k) grp.emplace_back(key[(size_t)k], idx[(size_t)k]);
-        std::sort(grp.begin(), grp.end(), [&](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
-          return a.first != b.first ? a.first < b.first : less(a.second, b.second);
-        });
-        for (int64_t k = g0; k < g1; ++k) idx[(size_t)k] = grp[(size_t)(k - g0)].second;
+    if (need <= 32) {
+      // (top 32 key bits, position) packed into one word: 16 bytes moved per element and pass
+      std::vector<uint64_t> kv((size_t)m), kv2((size_t)m);
+      {
+        uint64_t k = 0;   // symbols i .. i+per_key-1 in the top `used` bits, rolled in from the right
+        for (int64_t i = std::min<int64_t>(n, end + per_key) - 1; i >= beg; --i) {
+          k = (((uint64_t)code[text[i]] << (64 - bits)) | (k >> bits)) & keep;
+          if (i < end) kv[(size_t)(i - beg)] = (k & 0xFFFFFFFF00000000ull) | (uint64_t)(i - beg);
+        }
       }
-      g0 = g1;
+      for (int shift = 64 - need; shift < 64; shift += DB) {
+        const uint64_t dmask = ((uint64_t)1 << std::min(DB, 64 - shift)) - 1;
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (int64_t i = 0; i < m; ++i) ++cnt[(size_t)((kv[(size_t)i] >> shift) & dmask)];
+        uint32_t run = 0;
+        bool one_bucket = false;
+        for (size_t b = 0; b < cnt.size(); ++b) { uint32_t c = cnt[b]; if (c == (uint32_t)m) one_bucket = true; cnt[b] = run; run += c; }
+        if (one_bucket) continue;   // this digit is the same everywhere
+        for (int64_t i = 0; i < m; ++i) { const uint64_t v = kv[(size_t)i]; kv2[(size_t)(cnt[(size_t)((v >> shift) & dmask)]++)] = v; }
+        kv.swap(kv2);
+      }
+      std::vector<uint64_t>().swap(kv2);
+      const int gs = 64 - need, known = need / bits;   // a group = equal sorted bits = `known` whole symbols (at least)
+      for (int64_t g0 = 0; g0 < m;) {
+        int64_t g1 = g0 + 1;
+        while (g1 < m && (kv[(size_t)g1] >> gs) == (kv[(size_t)g0] >> gs)) ++g1;
+        if (g1 - g0 > 1) {
+          if (g1 - g0 > (1 << 16)) return false;
+          std::sort(kv.begin() + g0, kv.begin() + g1, [&](uint64_t a, uint64_t b) { return less_from((uint32_t)a, (uint32_t)b, known); });
+        }
+        g0 = g1;
+      }
+      for (int64_t i = 0; i < m; ++i) idx[(size_t)i] = (uint32_t)kv[(size_t)i];
+    } else {
+      std::vector<uint64_t> key((size_t)m), key2((size_t)m);
+      std::vector<uint32_t> idx2((size_t)m);
+      {
+        uint64_t k = 0;
+        for (int64_t i = std::min<int64_t>(n, end + per_key) - 1; i >= beg; --i) {
+          k = (((uint64_t)code[text[i]] << (64 - bits)) | (k >> bits)) & keep;
+          if (i < end) { key[(size_t)(i - beg)] = k; idx[(size_t)(i - beg)] = (uint32_t)(i - beg); }
+        }
+      }
+      for (int shift = 64 - need; shift < 64; shift += DB) {
+        const uint64_t dmask = ((uint64_t)1 << std::min(DB, 64 - shift)) - 1;
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (int64_t i = 0; i < m; ++i) ++cnt[(size_t)((key[(size_t)i] >> shift) & dmask)];
+        uint32_t run = 0;
+        bool one_bucket = false;
+        for (size_t b = 0; b < cnt.size(); ++b) { uint32_t c = cnt[b]; if (c == (uint32_t)m) one_bucket = true; cnt[b] = run; run += c; }
+        if (one_bucket) continue;
+        for (int64_t i = 0; i < m; ++i) {
+          const uint64_t kk = key[(size_t)i];
+          const uint32_t d = cnt[(size_t)((kk >> shift) & dmask)]++;
+          key2[(size_t)d] = kk; idx2[(size_t)d] = idx[(size_t)i];
+        }
+        key.swap(key2); idx.swap(idx2);
+      }
+      std::vector<uint64_t>().swap(key2);
+      std::vector<uint32_t>().swap(idx2);
+      const int gs = 64 - need;
+      std::vector<std::pair<uint64_t, uint32_t>> grp;
+      for (int64_t g0 = 0; g0 < m;) {
+        int64_t g1 = g0 + 1;
+        while (g1 < m && (key[(size_t)g1] >> gs) == (key[(size_t)g0] >> gs)) ++g1;
+        if (g1 - g0 > 1) {
+          if (g1 - g0 > (1 << 16)) return false;
+          grp.clear();
+          for (int64_t k = g0; k < g1; ++k) grp.emplace_back(key[(size_t)k], idx[(size_t)k]);
+          std::sort(grp.begin(), grp.end(), [&](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
+            return a.first != b.first ? a.first < b.first : less_from(a.second, b.second, per_key);
+          });
+          for (int64_t k = g0; k < g1; ++k) idx[(size_t)k] = grp[(size_t)(k - g0)].second;
+        }
+        g0 = g1;
+      }
     }
   } catch (const GtCapExceeded &) { return false; }
-  std::vector<uint64_t>().swap(key);
   out.beg = beg; out.size = m;
   out.psa_lo.swap(idx);
   out.psa_hi.clear();
