@@ -82,6 +82,39 @@ static inline void finish_halfblock(const uint8_t *text, int64_t n, int64_t beg,
   if (end < n && !gt_of_beg) out.gt_begin[0] |= 1u;
 }
 
+// gt_wrt_end for EVERY position s of [beg, e) in O(e - beg): the longest common prefix of text[s..e) with
+// text[e..) comes from the Z-function of text[e..e+m) (prefix matching), so periodic text costs no more than
+// random text.  (The reference gets the same bits from string matching as well: compute_initial_gt_bitvectors.hpp.)
+// bit (s - beg) of the result = [text[s..n) > text[e..n)].
+static inline std::vector<uint8_t> gt_all_wrt_end(const uint8_t *text, int64_t n, int64_t beg, int64_t e, const GtTail &gt_tail) {
+  const int64_t m = e - beg, lp = std::min<int64_t>(m, n - e);   // pattern P = text[e .. e+lp)
+  std::vector<uint8_t> bits((size_t)(m + 7) / 8 + 1, 0);
+  if (lp <= 0) {                                                   // e == n: every suffix is greater than the empty one
+    for (int64_t i = 0; i < m; ++i) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+    return bits;
+  }
+  const uint8_t *P = text + e, *T = text + beg;
+  std::vector<uint32_t> z((size_t)lp, 0);
+  z[0] = (uint32_t)lp;
+  for (int64_t i = 1, l = 0, r = 0; i < lp; ++i) {
+    int64_t k = i < r ? std::min<int64_t>(r - i, z[(size_t)(i - l)]) : 0;
+    while (i + k < lp && P[k] == P[i + k]) ++k;
+    z[(size_t)i] = (uint32_t)k;
+    if (i + k > r) { l = i; r = i + k; }
+  }
+  for (int64_t i = 0, l = 0, r = 0; i < m; ++i) {                  // k = lcp(T[i..m), P)
+    int64_t k = i < r ? std::min<int64_t>(r - i, z[(size_t)(i - l)]) : 0;
+    while (i + k < m && k < lp && T[i + k] == P[k]) ++k;
+    if (i + k > r) { l = i; r = i + k; }
+    const int64_t lim = m - i;                                     // symbols of the suffix that lie before e
+    bool g;
+    if (k < lim) g = k >= lp ? true : T[i + k] > P[k];             // P exhausted: text[e..n) is a proper prefix
+    else g = e + lim >= n ? true : !gt_tail(lim);                  // text[s..e) == text[e..e+lim): the tail decides
+    if (g) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+  }
+  return bits;
+}
+
 static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, int64_t end, const GtTail &gt_tail,
                                   HalfBlock &out, int64_t cap = 0) {
   const int64_t m = end - beg;
@@ -91,11 +124,18 @@ static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, i
   uint8_t last = blk[(size_t)m - 1];
   bool gt_of_beg = false;  // [text[beg..) > text[end..)]
   if (end < n) {
-    gt_of_beg = gt_wrt_end(text, n, beg, end, gt_tail, cap);
+    // sequential schedule (cap == 0): all gt bits at once, linear time; look-ahead (cap > 0): bounded direct
+    // comparisons, which give up on periodic text instead of asking for tail bits that do not exist yet
+    std::vector<uint8_t> gtb;
+    if (cap == 0) gtb = gt_all_wrt_end(text, n, beg, end, gt_tail);
+    auto gt_at = [&](int64_t i) {   // [text[beg+i ..) > text[end..)]
+      return cap == 0 ? (bool)((gtb[(size_t)(i >> 3)] >> (i & 7)) & 1) : gt_wrt_end(text, n, beg + i, end, gt_tail, cap);
+    };
+    gt_of_beg = gt_at(0);
     renamed = true;
     for (int64_t i = 0; i + 1 < m; ++i) {
       uint8_t c = blk[(size_t)i];
-      if (c > last || (c == last && gt_wrt_end(text, n, beg + i + 1, end, gt_tail, cap))) {
+      if (c > last || (c == last && gt_at(i + 1))) {
         if (c == 255) throw std::runtime_error("the input contains byte 255");
         blk[(size_t)i] = c + 1;
       }
