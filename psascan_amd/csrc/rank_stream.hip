@@ -1054,7 +1054,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   if (!lo || !hi || !fin) { set_error("stream: pinned host allocation failed"); return PSG_ENOMEM; }
   for (i64 k = 0; k < K; ++k) fin[k] = -1;
   std::vector<i64> list;
-  std::vector<char> resolved(K, 0), done(K, 0);
+  std::vector<char> resolved(K, 0);
   WarmParams WP{d_tail, T + ctx, ctx, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
   // warm-up with growing W for the chains that did not resolve
   i64 nun = 0;
@@ -1086,21 +1086,17 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
   // known once chain k-1 (to its right in the text) has finished: fin[k-1] == init[k].
-  std::vector<i64> ready;
+  // Host work per round is proportional to the chains of that round (a text whose chains all wait for their
+  // right neighbour runs K rounds of one chain: scanning all K chains per round would be quadratic).
+  std::vector<i64> ready, next, need;
+  const bool all_first = nun == 0;   // the usual case: every start rank came out of the warm-up
+  if (!all_first)
+    for (i64 k = 0; k < K; ++k) if (resolved[k]) ready.push_back(k);
+  const i64 SMALL = 256;             // up to this many values are moved one by one instead of as whole arrays
   while (ndone < K) {
-    ready.clear();
-    const bool all_ready = nun == 0;   // the usual case: every start rank came out of the warm-up
-    if (!all_ready)
-      for (i64 k = 0; k < K; ++k)
-        if (!done[k] && (resolved[k] || (k > 0 && done[k - 1]))) {
-          if (!resolved[k]) { lo[k] = fin[k - 1]; resolved[k] = 1; }
-          ready.push_back(k);
-        }
+    const bool all_ready = all_first || (i64)ready.size() == K;
     if (!all_ready && ready.empty()) { set_error("stream: no runnable chain (internal error)"); return PSG_ECHECK; }
-    if (nun > 0) {  // start ranks may have been patched on the host
-      PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));
-    }
-    if (all_ready || (i64)ready.size() == K) { SP.list = nullptr; SP.nchains = K; }
+    if (all_ready) { SP.list = nullptr; SP.nchains = K; }
     else {
       if (int rc_ = psg::copy_h2d(list_d.p, ready.data(), (size_t)(ready.size() * 8))) return rc_;
       SP.list = list_d.as<i64>(); SP.nchains = (i64)ready.size();
@@ -1109,13 +1105,29 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     DISPATCH_LAYOUT(r, launch_stream, r, SP, mode, cpl);
     ktm.stop();
     PSG_HIP(hipGetLastError());
-    PSG_HIP(hipMemcpyAsync(fin, fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(psg::sync_stream());
+    // final ranks that start a waiting chain: chain k+1 unresolved, chain k just run
+    need.clear();
+    if (!all_ready) for (i64 k : ready) if (k + 1 < K && !resolved[k + 1]) need.push_back(k);
+    if ((i64)need.size() > SMALL) {
+      PSG_HIP(hipMemcpyAsync(fin, fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+      PSG_HIP(psg::sync_stream());
+    } else {
+      for (i64 k : need) if (int rc_ = psg::copy_d2h(&fin[k], fin_d.as<i64>() + k, 8)) return rc_;
+      PSG_HIP(psg::sync_stream());
+    }
     kms += ktm.ms();
-    if (all_ready) ndone = K;
-    else { for (i64 k : ready) done[k] = 1; ndone += (i64)ready.size(); }
+    ndone += all_ready ? K : (i64)ready.size();
     st.rounds++;
+    next.clear();
+    for (i64 k : need) { lo[k + 1] = fin[k]; resolved[k + 1] = 1; next.push_back(k + 1); }
+    if (!next.empty()) {   // the patched start ranks go to the device
+      if ((i64)next.size() > SMALL) PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));
+      else for (i64 k : next) if (int rc_ = psg::copy_h2d(lo_d.as<i64>() + k, &lo[k], 8)) return rc_;
+    }
+    ready.swap(next);
   }
+  PSG_HIP(hipMemcpyAsync(fin, fin_d.p, K * 8, hipMemcpyDeviceToHost, stream()));   // all final ranks for the check below
+  PSG_HIP(psg::sync_stream());
   // invariant: the rank a chain ends with is the start rank of the next chain
   for (i64 k = 1; k < K; ++k)
     if (fin[k - 1] != lo[k]) {
