@@ -124,13 +124,13 @@ static inline void sort_halfblock(const uint8_t *text, int64_t n, int64_t beg, i
   uint8_t last = blk[(size_t)m - 1];
   bool gt_of_beg = false;  // [text[beg..) > text[end..)]
   if (end < n) {
-    // sequential schedule (cap == 0): all gt bits at once, linear time; look-ahead (cap > 0): bounded direct
-    // comparisons, which give up on periodic text instead of asking for tail bits that do not exist yet
-    std::vector<uint8_t> gtb;
-    if (cap == 0) gtb = gt_all_wrt_end(text, n, beg, end, gt_tail);
-    auto gt_at = [&](int64_t i) {   // [text[beg+i ..) > text[end..)]
-      return cap == 0 ? (bool)((gtb[(size_t)(i >> 3)] >> (i & 7)) & 1) : gt_wrt_end(text, n, beg + i, end, gt_tail, cap);
-    };
+    // all gt bits at once, in linear time (Z-function), in both schedules.  The tail oracle is only asked for a
+    // position whose whole in-block part matches the text behind `end`; in the look-ahead schedule (cap > 0) it is the
+    // bounded direct comparison, which gives up (GtCapExceeded) on periodic text instead of asking for tail bits
+    // that do not exist yet.  (Deciding every position by its own bounded comparison cost O(m * run length) on
+    // text with long runs of varying length -- zero-padded images -- without ever tripping the cap.)
+    const std::vector<uint8_t> gtb = gt_all_wrt_end(text, n, beg, end, gt_tail);
+    auto gt_at = [&](int64_t i) { return (bool)((gtb[(size_t)(i >> 3)] >> (i & 7)) & 1); };   // [text[beg+i ..) > text[end..)]
     gt_of_beg = gt_at(0);
     renamed = true;
     for (int64_t i = 0; i + 1 < m; ++i) {

@@ -63,12 +63,47 @@ static void gap_to_values(buffered_gap_array *g, uint64_t *out) {
 }
 
 static long g_threads = 2;
+static int g_uint40 = 0;   // 1: instantiate compute_gap / merge with T = uint40 (what psascan.hpp:117-125 picks for n >= 2^31)
+
+template <typename T>
+static int merge_T(int H, const long *beg, const long *size, const int *const *psa, const uint64_t *const *gap,
+                   long ram_use, const char *workdir, uint8_t *out_sa5) {
+  std::string wd(workdir), out_fn = wd + "/ref_merge_out.sa5";
+  std::vector<half_block_info<T> > hbs;
+  long n = 0;
+  silence(true);
+  for (int h = 0; h < H; ++h) {
+    half_block_info<T> hb;
+    hb.beg = beg[h]; hb.end = beg[h] + size[h]; n += size[h];
+    std::vector<T> vals((size_t)size[h]);
+    for (long k = 0; k < size[h]; ++k) vals[(size_t)k] = T((long)psa[h][k]);
+    hb.psa = new distributed_file<T>(out_fn, std::max(4L, ram_use / 20L), vals.data(), vals.data() + size[h]);
+    if (h + 1 < H) {
+      hb.gap_filename = wd + "/ref_gap." + utils::random_string_hash();
+      buffered_gap_array *g = gap_from_values(gap[h], size[h] + 1, wd + "/ref_excess4");
+      g->save_to_file(hb.gap_filename);
+      g->erase_disk_excess();
+      delete g;
+    }
+    hbs.push_back(hb);
+  }
+  double t0 = now_s();
+  merge<T>(out_fn, ram_use, hbs);
+  g_last_seconds = now_s() - t0;
+  silence(false);
+  unsigned char *buf = NULL; long len = 0;
+  utils::read_objects_from_file(buf, len, out_fn);
+  memcpy(out_sa5, buf, std::min(len, 5 * n)); free(buf);
+  utils::file_delete(out_fn);
+  return len == 5 * n ? 0 : 1;
+}
 
 extern "C" {
 
 double ref_last_seconds(void) { return g_last_seconds; }
 double ref_last_rank_build_seconds(void) { return g_rank_seconds; }
 void ref_set_threads(long t) { g_threads = t > 0 ? t : 1; }
+void ref_set_uint40(int on) { g_uint40 = on ? 1 : 0; }
 
 // rank4n<>::rank (rank.hpp:566-708) and m_count (rank.hpp:112)
 int ref_rank(const uint8_t *bwt, long m, const long *qi, const uint8_t *qc, long nq, long *out, long *counts256) {
@@ -105,7 +140,8 @@ int ref_compute_gap(const uint8_t *bwt, long m, long i0, int last, const uint8_t
   std::vector<long> ir(init_ranks, init_ranks + n_threads);
   silence(true);
   double t0 = now_s();
-  compute_gap<int>(r, gap, tb, te, n, n_threads, i0, 1L << 21, (unsigned char)last, ir, text_fn, base, gt_in_mf, gt_out_mf);
+  if (g_uint40) compute_gap<uint40>(r, gap, tb, te, n, n_threads, i0, 1L << 21, (unsigned char)last, ir, text_fn, base, gt_in_mf, gt_out_mf);
+  else compute_gap<int>(r, gap, tb, te, n, n_threads, i0, 1L << 21, (unsigned char)last, ir, text_fn, base, gt_in_mf, gt_out_mf);
   g_last_seconds = now_s() - t0;
   silence(false);
   gap_to_values(gap, gap_out);
@@ -208,35 +244,11 @@ long ref_gap_save_vbyte(const uint64_t *gap, long len, const char *workdir, uint
   return nb;
 }
 
-// merge<int> (merge.hpp:55-180). psa[h] int32 relative to beg[h]; gap[h] u64[size+1] for h < H-1.
+// merge<T> (merge.hpp:55-180), T = int or uint40. psa[h] int32 relative to beg[h]; gap[h] u64[size+1] for h < H-1.
 int ref_merge(int H, const long *beg, const long *size, const int *const *psa, const uint64_t *const *gap,
               long ram_use, const char *workdir, uint8_t *out_sa5) {
-  std::string wd(workdir), out_fn = wd + "/ref_merge_out.sa5";
-  std::vector<half_block_info<int> > hbs;
-  long n = 0;
-  silence(true);
-  for (int h = 0; h < H; ++h) {
-    half_block_info<int> hb;
-    hb.beg = beg[h]; hb.end = beg[h] + size[h]; n += size[h];
-    hb.psa = new distributed_file<int>(out_fn, std::max(4L, ram_use / 20L), psa[h], psa[h] + size[h]);
-    if (h + 1 < H) {
-      hb.gap_filename = wd + "/ref_gap." + utils::random_string_hash();
-      buffered_gap_array *g = gap_from_values(gap[h], size[h] + 1, wd + "/ref_excess4");
-      g->save_to_file(hb.gap_filename);
-      g->erase_disk_excess();
-      delete g;
-    }
-    hbs.push_back(hb);
-  }
-  double t0 = now_s();
-  merge<int>(out_fn, ram_use, hbs);
-  g_last_seconds = now_s() - t0;
-  silence(false);
-  unsigned char *buf = NULL; long len = 0;
-  utils::read_objects_from_file(buf, len, out_fn);
-  memcpy(out_sa5, buf, std::min(len, 5 * n)); free(buf);
-  utils::file_delete(out_fn);
-  return len == 5 * n ? 0 : 1;
+  return g_uint40 ? merge_T<uint40>(H, beg, size, psa, gap, ram_use, workdir, out_sa5)
+                  : merge_T<int>(H, beg, size, psa, gap, ram_use, workdir, out_sa5);
 }
 
 }  // extern "C"

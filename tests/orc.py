@@ -216,6 +216,7 @@ def ref_lib():
     L.ref_gap_to_bitvector.argtypes = [u64p, C.c_long, C.c_char_p, u8p, C.c_long]
     L.ref_merge_bwt.argtypes = [u8p, u8p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, u8p, u8p]
     L.ref_merge_bwt.restype = C.c_long
+    L.ref_set_uint40.argtypes = [C.c_int]
     for f in (L.ref_right_gap, L.ref_left_gap):
         f.argtypes = [u64p, u8p, C.c_long, C.c_long, C.c_char_p, u64p, u8p, C.POINTER(C.c_long)]
     L.ref_gap_save_vbyte.argtypes = [u64p, C.c_long, C.c_char_p, u8p]

@@ -207,9 +207,20 @@ def test_ref_rank():
         assert np.array_equal(out, np.array([rk.rank(i, c) for i, c in zip(qi, qc)], np.int64))
 
 
+@pytest.fixture(params=["int", "uint40"])
+def ref_T(request):
+    """The reference instantiates compute_gap<T> / merge<T> with int below 2^31 symbols and uint40 above
+    (psascan.hpp:117-125): every BASELINE config from configs[1] on runs the uint40 code.  Pin both."""
+    if REF is not None:
+        REF.ref_set_uint40(1 if request.param == "uint40" else 0)
+    yield request.param
+    if REF is not None:
+        REF.ref_set_uint40(0)
+
+
 @needs_ref
 @pytest.mark.parametrize("name", ["sig4z", "rand255", "alla", "fib"])
-def test_ref_block_stages(name, wd):
+def test_ref_block_stages(name, wd, ref_T):
     t, n, b, mid, e, sa, isa = _block_case(name)
     ml, mr = mid - b, e - mid
     lpsa, lbwt, li0, _ = orc.partial_sa(t, sa, isa, b, mid)
@@ -274,7 +285,7 @@ def test_ref_big_gap_values_and_vbyte(wd):
 
 
 @needs_ref
-def test_ref_merge(wd):
+def test_ref_merge(wd, ref_T):
     rng = np.random.default_rng(11)
     t = rng.integers(0, 3, 5000, dtype=np.uint8)
     n = len(t)
