@@ -17,8 +17,10 @@
  *   - a "gt" bit array that belongs to the position range (lo, hi] stores the bit of text
  *     position j at index u = hi - j.  This is the reference's reversed indexing (bit n-j
  *     of the multifile, compute_gap.hpp:118-119, stream.hpp:104-106) shifted by n-hi.
- *   - one host thread drives one device; work is enqueued on the library's stream and the
- *     call returns after the result is complete unless stated otherwise.
+ *   - ONE host thread per process drives ONE device (the library keeps its stream, device arena and
+ *     staging buffers in process-wide state; the multi-GPU driver runs one process per GPU); work is
+ *     enqueued on the library's stream and the call returns after the result is complete unless
+ *     stated otherwise.  psg_last_error() is per thread.
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
  */
 #ifndef PSASCAN_AMD_H

@@ -100,6 +100,10 @@ static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
 // LDS-sized windows -- replaces one random atomic per streamed suffix (gap_hist.hip).
 // overwrite: d_gap holds garbage on entry and exactly the histogram on return (no zero-fill needed)
 int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
+// the same for ranks of up to 40 bits (blocks of >= 2^32 - 1 symbols): log_lo holds the low words, log_hi one byte per
+// entry with bits 32..39 (no entry = 0xFFFFFFFF / 0xFF).  The log is first split into slabs of 2^31 counters (values
+// relative to the slab start), each slab is then histogrammed like a 32-bit log.  Both buffers are released.
+int gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
 // the same in two halves: launch enqueues everything on stream() without waiting for the device, wait
 // blocks until the job is done, checks the overflow flag and releases the job's buffers
 struct HistJob {

@@ -217,19 +217,45 @@ __device__ __forceinline__ u32 p2_bin(u32 v, int shift, u32 base) {
   return b < PBINS - 1 ? b : PBINS - 1;
 }
 
+// Key sources of a partition pass: entry -> (value to write, bin).
+struct Keys32 {            // a 32-bit rank log: bin = (v >> shift) - base, see p2_bin
+  const u32 *k; int shift; u32 base;
+  template <int EPT> __device__ __forceinline__ void load_tile(u32 (&v)[EPT], u32 (&b)[EPT], i64 beg, i64 end) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { i64 i = beg + j * P2T + threadIdx.x; v[j] = i < end ? k[i] : PAD; b[j] = p2_bin(v[j], shift, base); }
+  }
+};
+struct Keys40 {            // ranks of up to 40 bits in two planes (stream kernel MODE 3): bin = slab of 2^slab_shift counters,
+  const u32 *lo; const u8 *hi; int slab_shift;   // value = rank relative to the slab start.  beg, end multiples of 4.
+  template <int EPT> __device__ __forceinline__ void load_tile(u32 (&v)[EPT], u32 (&b)[EPT], i64 beg, i64 end) const {
+    static_assert(EPT % 4 == 0, "four consecutive entries per thread and load");
+#pragma unroll
+    for (int jj = 0; jj < EPT / 4; ++jj) {
+      const i64 i = beg + ((i64)jj * P2T + threadIdx.x) * 4;
+      uint4 l = make_uint4(PAD, PAD, PAD, PAD);
+      u32 h = 0xFFFFFFFFu;
+      if (i < end) { l = *(const uint4 *)(lo + i); h = *(const u32 *)(hi + i); }
+      const u32 lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32 hb = (h >> (8 * q)) & 255u;
+        const u64 x = ((u64)hb << 32) | lw[q];
+        const u32 sl = (u32)(x >> slab_shift);
+        b[4 * jj + q] = sl < PBINS - 1 ? sl : PBINS - 1;
+        v[4 * jj + q] = (lw[q] == PAD && hb == 0xFFu) ? PAD : (u32)(x & ((1ull << slab_shift) - 1ull));
+      }
+    }
+  }
+};
+
 // EPT entries per thread: a tile should bring ~4 entries per bin in use, so that the 16 slots of headroom
 // above the flush threshold are practically never exceeded
 template <int EPT>
-__device__ __forceinline__ void p2_load_tile(u32 (&v)[EPT], const u32 *keys, i64 beg, i64 end) {
-#pragma unroll
-  for (int j = 0; j < EPT; ++j) { i64 k = beg + j * P2T + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
-}
-template <int EPT>
-__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 (&v)[EPT], int shift, u32 base, u32 *out) {
+__device__ __forceinline__ void p2_insert_tile(Stage2 &S, const u32 (&v)[EPT], const u32 (&bn)[EPT], u32 *out) {
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     if (v[j] == PAD) continue;
-    const u32 b = p2_bin(v[j], shift, base);
+    const u32 b = bn[j];
     const u32 slot = atomicAdd(&S.cnt[b], 1u);
     if (slot < P2C) S.buf[b][slot] = v[j];
     else out[atomicAdd((unsigned long long *)&S.cur[b], 1ull)] = v[j];   // bin full between two flushes: rare, written directly
@@ -281,33 +307,33 @@ __device__ __forceinline__ void p2_flush_final(Stage2 &S, u32 *out) {
   }
 }
 
-// all tiles of keys[beg0, end0): the loads of the next tile are in flight while this one is inserted and flushed
-template <int EPT>
-__device__ __forceinline__ void p2_run(Stage2 &S, const u32 *keys, i64 beg0, i64 end0, int shift, u32 base, u32 *out) {
-  u32 v[EPT], vn[EPT];
-  p2_load_tile<EPT>(v, keys, beg0, end0);
+// all tiles of the entries [beg0, end0): the loads of the next tile are in flight while this one is inserted and flushed
+template <int EPT, class KEYS>
+__device__ __forceinline__ void p2_run(Stage2 &S, const KEYS &keys, i64 beg0, i64 end0, u32 *out) {
+  u32 v[EPT], b[EPT], vn[EPT], bn[EPT];
+  keys.template load_tile<EPT>(v, b, beg0, end0);
   for (i64 beg = beg0; beg < end0; beg += EPT * P2T) {
-    p2_load_tile<EPT>(vn, keys, beg + EPT * P2T, end0);
-    p2_insert_tile<EPT>(S, v, shift, base, out);
+    keys.template load_tile<EPT>(vn, bn, beg + EPT * P2T, end0);
+    p2_insert_tile<EPT>(S, v, b, out);
     p2_flush(S, out);
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v[j] = vn[j];
+    for (int j = 0; j < EPT; ++j) { v[j] = vn[j]; b[j] = bn[j]; }
   }
   p2_flush_final(S, out);
 }
 
 // level 1, step A: workgroup g counts the entries of its chunk [g*chunk, (g+1)*chunk)
-__global__ __launch_bounds__(P2T) void p2_count_kernel(const u32 *keys, i64 n, i64 chunk, int shift, u32 *counts) {
+template <class KEYS>
+__global__ __launch_bounds__(P2T) void p2_count_kernel(KEYS keys, i64 n, i64 chunk, u32 *counts) {
   __shared__ u32 h[PBINS];
   for (int b = threadIdx.x; b < PBINS; b += P2T) h[b] = 0;
   __syncthreads();
   const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
-  for (i64 k0 = cb; k0 < ce; k0 += 8 * P2T) {
-    u32 v[8];
+  for (i64 k0 = cb; k0 < ce; k0 += 8 * P2T) {   // 8 independent loads in flight, then the LDS atomics
+    u32 v[8], bn[8];
+    keys.template load_tile<8>(v, bn, k0, ce);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < ce ? keys[k] : PAD; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[p2_bin(v[j], shift, 0)], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[bn[j]], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < PBINS; b += P2T) counts[(i64)blockIdx.x * PBINS + b] = h[b];
@@ -333,13 +359,14 @@ __global__ __launch_bounds__(PBINS) void p2_offsets_kernel(const u32 *counts, in
 }
 
 // level 1, step C
-__global__ __launch_bounds__(P2T) void p2_scatter_kernel(const u32 *keys, i64 n, i64 chunk, int shift, const u64 *off, u32 *out) {
+template <class KEYS>
+__global__ __launch_bounds__(P2T) void p2_scatter_kernel(KEYS keys, i64 n, i64 chunk, const u64 *off, u32 *out) {
   __shared__ Stage2 S;
   for (int b = threadIdx.x; b < PBINS; b += P2T) { S.cur[b] = off[(i64)blockIdx.x * PBINS + b]; S.cnt[b] = 0; }
   if (threadIdx.x == 0) S.nlist = 0;
   __syncthreads();
   const i64 cb = (i64)blockIdx.x * chunk, ce = std::min<i64>(cb + chunk, n);
-  p2_run<P2TS / P2T>(S, keys, cb, ce, shift, 0u, out);
+  p2_run<P2TS / P2T>(S, keys, cb, ce, out);
 }
 
 // level 2: workgroup b splits level-1 bin b (keys[bin_base[b] .. bin_base[b+1]), padding included) into its
@@ -372,9 +399,10 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   if (blockIdx.x == PBINS - 1 && threadIdx.x == 0) win_off[nwin] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  if (nsub > P2L2_A) p2_run<P2L2_EA>(S, keys, sb, se, WBITS, base, out);
-  else if (nsub > P2L2_B) p2_run<P2L2_EB>(S, keys, sb, se, WBITS, base, out);
-  else p2_run<1>(S, keys, sb, se, WBITS, base, out);
+  const Keys32 K2{keys, WBITS, base};
+  if (nsub > P2L2_A) p2_run<P2L2_EA>(S, K2, sb, se, out);
+  else if (nsub > P2L2_B) p2_run<P2L2_EB>(S, K2, sb, se, out);
+  else p2_run<1>(S, K2, sb, se, out);
 }
 
 // work items per window; all_windows: at least one each (the overwriting histogram must visit empty windows too)
@@ -478,9 +506,10 @@ int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bo
   if ((rc = J.part1.alloc(cap1 * 4)) || (rc = J.counts.alloc((i64)G * PBINS * 4)) || (rc = J.off.alloc((i64)G * PBINS * 8)) ||
       (rc = J.bin_base.alloc((PBINS + 1) * 8)) || (rc = J.win_off.alloc((nwin_slots + 1) * 8)) || (rc = J.cnt.alloc(nwin_slots * 8)) || (rc = J.tot.alloc(8)))
     return rc;
-  hipLaunchKernelGGL(p2_count_kernel, dim3(G), dim3(P2T), 0, J.s, d_log, nlog, chunk, shift1, J.counts.as<u32>());
+  const Keys32 K1{d_log, shift1, 0u};
+  hipLaunchKernelGGL(p2_count_kernel<Keys32>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.counts.as<u32>());
   hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, J.s, J.counts.as<u32>(), G, J.off.as<u64>(), J.bin_base.as<u64>());
-  hipLaunchKernelGGL(p2_scatter_kernel, dim3(G), dim3(P2T), 0, J.s, d_log, nlog, chunk, shift1, J.off.as<u64>(), J.part1.as<u32>());
+  hipLaunchKernelGGL(p2_scatter_kernel<Keys32>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.off.as<u64>(), J.part1.as<u32>());
   PSG_HIP(hipGetLastError());
   const u32 *sorted = J.part1.as<u32>();
   const u64 *woff = J.bin_base.as<u64>();
@@ -529,6 +558,53 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, 
   HistJob job;
   if (int rc = gap_hist_launch(job, d_log, nlog, m, d_gap, overwrite)) return rc;
   return gap_hist_wait(job, ms);
+}
+
+// Ranks of up to 40 bits (m >= 2^32 - 1): split the two-plane log into slabs of 2^slab_shift counters with the
+// level-1 machinery (bin = slab, values relative to the slab start, segments padded to whole units), then run the
+// 32-bit histogram on every slab.  PSG_LOG_SLAB_SHIFT makes the slabs small so that tests cross several of them.
+int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
+  int slab_shift = 31;
+  if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 31) slab_shift = v; }
+  while (((m >> slab_shift) + 1) > PBINS) ++slab_shift;   // at most 512 slabs (only reachable with a test-sized shift)
+  if (slab_shift > 31) { set_error("gap histogram: block too large"); return PSG_EINVAL; }
+  const i64 nslab = (m >> slab_shift) + 1;
+  EventTimer tm;
+  tm.start();
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, P2TS)));
+  const i64 chunk = cdiv(cdiv(nlog, G), P2TS) * P2TS;
+  DevBuf slabs, counts, off, bin_base;
+  int rc;
+  const i64 cap = nlog + P2SLACK * G + 64;
+  if ((rc = slabs.alloc(cap * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) || (rc = bin_base.alloc((PBINS + 1) * 8))) return rc;
+  const Keys40 K0{log_lo.as<u32>(), log_hi.as<u8>(), slab_shift};
+  hipLaunchKernelGGL(p2_count_kernel<Keys40>, dim3(G), dim3(P2T), 0, stream(), K0, nlog, chunk, counts.as<u32>());
+  hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
+  hipLaunchKernelGGL(p2_scatter_kernel<Keys40>, dim3(G), dim3(P2T), 0, stream(), K0, nlog, chunk, off.as<u64>(), slabs.as<u32>());
+  PSG_HIP(hipGetLastError());
+  u64 *bb = (u64 *)pinned_buf(4, (PBINS + 1) * 8);
+  if (!bb) { set_error("gap histogram: pinned host allocation failed"); return PSG_ENOMEM; }
+  PSG_HIP(hipMemcpyAsync(bb, bin_base.p, (PBINS + 1) * 8, hipMemcpyDeviceToHost, stream()));
+  tm.stop();
+  PSG_HIP(psg::sync_stream());
+  double total = tm.ms();
+  log_lo.alloc(16); log_hi.alloc(16);   // the planes are dead: their memory serves the per-slab partitions
+  for (i64 sl = 0; sl < nslab; ++sl) {
+    const i64 base = sl << slab_shift, ms_ = std::min<i64>(((i64)1 << slab_shift) - 1, m - base);   // counters [0, ms_] of this slab
+    const i64 beg = (i64)bb[sl], cnt = (i64)bb[sl + 1] - beg;
+    if (cnt == 0) {
+      if (overwrite) PSG_HIP(hipMemsetAsync(d_gap + base, 0, (size_t)(ms_ + 1) * 4, stream()));
+      continue;
+    }
+    double t = 0;
+    if ((rc = gap_hist_from_log(slabs.as<u32>() + beg, cnt, ms_, d_gap + base, &t, overwrite))) return rc;
+    total += t;
+  }
+  if (ms) *ms = total;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -49,6 +49,25 @@ extern "C" int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, ui
 
 struct KeyCfg { int bits, per_key; u8 code[256]; };
 
+// flags[c] = 1 for every byte value that occurs in text[0..n)
+__global__ __launch_bounds__(PSG_WG) void present_kernel(const u8 *text, i64 n, u32 *flags) {
+  __shared__ u32 f[256];
+  f[threadIdx.x] = 0;
+  __syncthreads();
+  for (i64 k = ((i64)blockIdx.x * PSG_WG + threadIdx.x) * 16; k < n; k += (i64)gridDim.x * PSG_WG * 16) {
+    if (k + 16 <= n && ((uintptr_t)text & 15) == 0) {
+      const uint4 v = *(const uint4 *)(text + k);
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) f[(w[q >> 2] >> (8 * (q & 3))) & 255u] = 1u;
+    } else {
+      for (i64 j = k; j < n && j < k + 16; ++j) f[text[j]] = 1u;
+    }
+  }
+  __syncthreads();
+  if (f[threadIdx.x]) flags[threadIdx.x] = 1u;
+}
+
 __global__ __launch_bounds__(PSG_WG) void make_keys_kernel(const u8 *text, i64 n, i64 beg, i64 size, KeyCfg cfg, u64 *keys, u32 *idx) {
   i64 s = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (s >= size) return;
@@ -115,16 +134,18 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
                                    int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups) {
   i64 size = end - beg;
   PSG_REQUIRE(d_text && d_psa && d_bwt && i0 && size >= 1 && size < (1ll << 32) && end <= n && beg >= 0, "psgx_sort_halfblock");
-  // alphabet of the whole text -> bits per symbol
+  // alphabet of the WHOLE text -> bits per symbol (a symbol that first appears late must get its own code)
   DevBuf hist;
   int rc;
-  if ((rc = hist.alloc(256 * 8))) return rc;
-  // reuse the rank histogram through a tiny local kernel: count on a sample is not enough, do it exactly
-  std::vector<u8> sample((size_t)std::min<i64>(n, 1 << 22));
-  if (int rc_ = psg::copy_d2h(sample.data(), d_text, (size_t)(sample.size()))) return rc_;
+  if ((rc = hist.alloc(256 * 4))) return rc;
+  PSG_HIP(hipMemsetAsync(hist.p, 0, 256 * 4, stream()));
+  hipLaunchKernelGGL(present_kernel, dim3((unsigned)std::min<i64>(cdiv(n, (i64)PSG_WG * 16), 4096)), dim3(PSG_WG), 0, stream(), d_text, n, hist.as<u32>());
+  PSG_HIP(hipGetLastError());
+  u32 hflags[256];
+  if (int rc_ = psg::copy_d2h(hflags, hist.p, sizeof hflags)) return rc_;
   PSG_HIP(psg::sync_stream());
-  bool present[256] = {false};
-  for (u8 c : sample) present[c] = true;
+  bool present[256];
+  for (int c = 0; c < 256; ++c) present[c] = hflags[c] != 0;
   KeyCfg cfg;
   int sigma = 0;
   for (int c = 0; c < 256; ++c) sigma += present[c];

@@ -135,10 +135,17 @@ __device__ __forceinline__ void sm_dense_flush(SmDense &D, const u8 *sym, i64 ba
   if (threadIdx.x == 0) D.n = 0;
 }
 
+// occurrences of every symbol before superblock sb (superblock = 2^sbs segments): workgroup sb, thread c
+__global__ __launch_bounds__(256) void sm_sb_base_kernel(const u32 *seg_pref, const u64 *group_base, int sbs, u64 *sb_base) {
+  const i64 seg0 = (i64)blockIdx.x << sbs;
+  sb_base[(i64)blockIdx.x * 256 + threadIdx.x] = group_base[(seg0 / GROUP_SEGS) * 256 + threadIdx.x] + seg_pref[seg0 * 256 + threadIdx.x];
+}
+
 // L8: the LIST symbols of this structure use 8-byte entries (SM_LIST8) -- all of them or none
+// sbs: log2(segments per superblock); the counts stored in the entries are relative to the superblock start
 template <bool L8>
 __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, const u64 *t2g, const u32 *seg_pref, const u64 *group_base,
-                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err) {
+                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err, int sbs) {
   __shared__ __attribute__((aligned(16))) u8 sym[SM_SEG];
   __shared__ __attribute__((aligned(16))) SmPhaseLds P;
   __shared__ u64 t2S[256];
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   }
   __syncthreads();
   if (mymode == SM_BITMAP) { int k = atomicAdd(&nbm, 1); if (k < SM_MAX_BITMAP) bmSym[k] = (u8)c; }
-  u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c]);
+  const i64 seg0 = (seg >> sbs) << sbs;   // first segment of this superblock
+  u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c] - (group_base[(seg0 / GROUP_SEGS) * 256 + c] + seg_pref[seg0 * 256 + c]));
   // ---------------- LIST8 symbols: one phase over the 16 buckets, runs of 16 entries = one 128-byte line ----------------
   if (L8) {
     for (int k = c; k < 16 * SM_OUT_STRIDE; k += 256) P.L8.slot[k] = make_uint2(0u, ~0u);

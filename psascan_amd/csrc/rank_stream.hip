@@ -1,7 +1,8 @@
 // rank_stream.hip -- K1 (rank structure build) and K2 (streaming gap kernel) for gfx950.
 //
-// Default rank layout: symbol-major entries, one 8/16-byte load per query (rank_sm.hpp).  Fallback for
-// blocks of >= 2^32 - 1 symbols, or when that structure does not fit the HBM budget:
+// Default rank layout: symbol-major entries, one 8/16-byte load per query (rank_sm.hpp), for blocks of any
+// size (counts are kept relative to superblocks of 2^31 positions, the bases live in the LDS table of the
+// pass).  Fallback when that structure does not fit the HBM budget:
 // "interleaved blocks" (HBM-resident): the BWT is cut into blocks of B data
 // bytes; each block is stored as  [CNT x u32 counters][B data bytes]  (STRIDE = 4*CNT+B).
 // counter[code] = #occurrences of that symbol before the block, relative to the enclosing
@@ -25,7 +26,7 @@ using namespace psg;
 #ifndef PSG_STREAM_MIN_WAVES
 #define PSG_STREAM_MIN_WAVES 1      // waves per SIMD requested from the register allocator (B <= 64 layouts)
 #endif
-#define SB_SHIFT 24                 // blocks per superblock = 2^24
+#define SB_SHIFT_DEFAULT 24         // interleaved blocks: blocks per superblock = 2^24 (PSG_BLOCK_SB_SHIFT: tests)
 #define SEG_BLOCKS 64               // blocks per build segment (one workgroup)
 #define GROUP_SEGS 256              // segments per scan group
 #define CODE_SHIFT 56
@@ -36,6 +37,7 @@ struct psg_rank {
   int cnt = 0, B = 0, stride = 0;
   i64 nblk = 0, nseg = 0;
   int nsb = 0;
+  int sb_shift = 0;               // log2(positions per superblock) (symbol-major) / log2(blocks per superblock) (interleaved blocks)
   u8 *d_blocks = nullptr;
   i64 blocks_bytes = 0;
   u64 *d_sb = nullptr;            // [nsb][cnt]
@@ -125,6 +127,7 @@ template <int CNT, int B> struct RankView {   // CNT == 0: symbol-major layout (
   const u8 *blocks;
   i64 m;
   const u8 *aux;                                     // symbol-major layout: overflow bitmap pool
+  int sb_shift;                                      // log2(positions | blocks per superblock)
   static constexpr int STRIDE = 4 * CNT + B;
   static constexpr int MID = B == 48 ? 32 : B / 2;   // multiple of 16, >= B - MID
 };
@@ -152,7 +155,9 @@ template <int CNT, int B> struct RankReq {
 
 template <int CNT, int B>
 __device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c, RankReq<CNT, B> &q) {
-  u64 e0 = T1[c];
+  // symbol-major layout: the entry's count is relative to the superblock of i, whose base is folded into T1
+  const i64 sbi = (CNT == 0 && i > 0 && i < R.m) ? (i >> R.sb_shift) : 0;
+  u64 e0 = T1[sbi * 256 + c];
   u32 code = (u32)(e0 >> CODE_SHIFT);
   i64 Cc = (i64)(e0 & VAL_MASK);
   q.kind = 0;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 
     const uint4 *dp = (const uint4 *)(p + 4 * CNT + (q.upper ? MID : 0));
 #pragma unroll
     for (int k = 0; k < MID / 16; ++k) q.d[k] = dp[k];
-    i64 sb = blk >> SB_SHIFT;
+    i64 sb = blk >> R.sb_shift;
     q.res = sb ? (i64)(T1[sb * 256 + c] & VAL_MASK) : Cc;
     q.kind = 1;
   }
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(PSG_WG) void group_scan_kernel(u64 *group_sum, i64 
 // (high half), so the midpoint counter and the running prefix come out of one array.
 template <int CNT, int B>
 __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m, const u8 *code_g, const u32 *seg_pref,
-                                                             const u64 *group_base, u8 *blocks, i64 nblk) {
+                                                             const u64 *group_base, u8 *blocks, i64 nblk, int sb_shift) {
   constexpr int SEGSYM = SEG_BLOCKS * B;
   constexpr int STRIDE = 4 * CNT + B;
   constexpr int MID = RankView<CNT, B>::MID;
@@ -314,8 +319,8 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
   }
   // running count (relative to the superblock) at the start of the segment, for the code of this thread
   const i64 g = seg / GROUP_SEGS;
-  const i64 sb = (seg * SEG_BLOCKS) >> SB_SHIFT;
-  const i64 sb_group = (sb << SB_SHIFT) / SEG_BLOCKS / GROUP_SEGS;
+  const i64 sb = (seg * SEG_BLOCKS) >> sb_shift;
+  const i64 sb_group = (sb << sb_shift) / SEG_BLOCKS / GROUP_SEGS;
   u32 run = 0;
   if (threadIdx.x < CNT) run = (u32)(group_base[g * CNT + threadIdx.x] + seg_pref[seg * CNT + threadIdx.x] - group_base[sb_group * CNT + threadIdx.x]);
   for (int half = 0; half < 2; ++half) {
@@ -390,13 +395,16 @@ struct StreamParams {
   const u64 *g_tot;
   int nsb;
   int *ovf_flag;
-  u32 *log;           // MODE 2: rank log, entry (step within chain) * K + chain
+  u32 *log;           // MODE 2/3: rank log (low 32 bits), entry ((step >> 2) * K + chain) * 4 + (step & 3)
   i64 K;              // total number of chains (log row length)
+  u32 *log_hi;        // MODE 3: bits 32..39 of the ranks, one byte per entry at the same index (0xFF + low word PAD = no entry)
 };
 
 // MODE 0: atomicAdd on the gap counters; 1: same with u32 overflow detection;
 // MODE 2: no atomics -- the ranks are logged (coalesced dwordx4 stores) and histogrammed afterwards
 //         (gap_hist.hip).
+// MODE 3: MODE 2 for blocks of >= 2^32 - 1 symbols: a second plane takes bits 32..39 of every rank (one dword
+//         store per 4 steps); the log is split into slabs of 2^31 counters before the histogram.
 // CPL = chains per lane: the steps of CPL independent chains are interleaved so that a lane has CPL
 //       rank loads in flight (memory-level parallelism beyond what 8 waves per SIMD give).
 struct Chain {
@@ -408,6 +416,7 @@ struct Chain {
   const uint4 *bp;    // 16-byte load of a chain costs a full random HBM access, ~like a rank load)
   uintptr_t last_addr;
   u32 gin, gin_next, gout;
+  u32 hiacc;          // MODE 3: high bytes of the last (t & 3) ranks
 };
 
 // the 64-byte text block at bp; its 16-byte chunks are consumed in descending order starting with chunk
@@ -440,7 +449,7 @@ template <int CNT, int B, int MODE, int CPL>
 __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
   constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
-  __shared__ u32 lstage[MODE == 2 ? CPL * 4 * PSG_WG : 1];
+  __shared__ u32 lstage[MODE >= 2 ? CPL * 4 * PSG_WG : 1];
   __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
   const bool gt16 = P.gt_out && ((uintptr_t)P.gt_out & 15) == 0 && (P.L & 127) == 0;
   load_tables(lds, P.g_T1, P.g_tot, P.nsb);
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
     c.u1 = act ? std::min<i64>(c.u0 + P.L, P.T) : 0;
     c.i = act ? P.init[c.k] : 0;
     c.w = c.u0 >> 5;
-    c.gin = 0; c.gin_next = 0; c.gout = 0;
+    c.gin = 0; c.gin_next = 0; c.gout = 0; c.hiacc = 0;
     c.tcnt = 1; c.thi = 0; c.tlo = 0; c.bp = nullptr; c.last_addr = 0; c.nbuf = 0;
     c.b0 = make_uint4(0, 0, 0, 0); c.b1 = c.b0; c.b2 = c.b0;
     if (act) {
@@ -513,14 +522,16 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
           ni -= (gti0[q] && sym[q] == 0) ? 1 : 0;
           ni += (sym[q] == P.last && ((c.gin >> t) & 1u)) ? 1 : 0;
           c.i = ni;
-          if (MODE == 2) {
+          if (MODE >= 2) {
             // 4 consecutive ranks of a chain leave as ONE dwordx4 store (memory instructions per step
             // are the scarce resource of this kernel); lane-private LDS slots, no barrier needed
             u32 *ls = lstage + q * 4 * PSG_WG;
             ls[(t & 3) * PSG_WG + threadIdx.x] = (u32)ni;
+            if (MODE == 3) c.hiacc |= (u32)((u64)ni >> 32) << (8 * (t & 3));
             if ((t & 3) == 3) {
               uint4 q4 = make_uint4(ls[threadIdx.x], ls[PSG_WG + threadIdx.x], ls[2 * PSG_WG + threadIdx.x], ls[3 * PSG_WG + threadIdx.x]);
               ((uint4 *)P.log)[((g + t) >> 2) * P.K + c.k] = q4;
+              if (MODE == 3) { P.log_hi[((g + t) >> 2) * P.K + c.k] = c.hiacc; c.hiacc = 0; }
             }
           } else if (CHECK_OVF) {
             u32 old = atomicAdd(&P.gap[ni], 1u);
@@ -566,12 +577,13 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
         }
         c.gin = c.gin_next;
         ++c.w;
-        if (MODE == 2 && (steps[q] & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
+        if (MODE >= 2 && (steps[q] & 3)) {   // ragged end of the last chain: flush the partial group, rest = no entry
           int full = steps[q] & ~3;
           const u32 *ls = lstage + q * 4 * PSG_WG;
           uint4 q4 = make_uint4(ls[threadIdx.x], (steps[q] & 3) > 1 ? ls[PSG_WG + threadIdx.x] : 0xFFFFFFFFu,
                                 (steps[q] & 3) > 2 ? ls[2 * PSG_WG + threadIdx.x] : 0xFFFFFFFFu, 0xFFFFFFFFu);
           ((uint4 *)P.log)[((g + full) >> 2) * P.K + c.k] = q4;
+          if (MODE == 3) { P.log_hi[((g + full) >> 2) * P.K + c.k] = c.hiacc | (0xFFFFFFFFu << (8 * (steps[q] & 3))); c.hiacc = 0; }
         }
       }
     }
@@ -580,9 +592,11 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
   for (int q = 0; q < CPL; ++q) {
     Chain &c = S[q];
     if (c.k < 0) continue;
-    if (MODE == 2)   // a short (last) chain marks the rest of its log column as "no entry"
-      for (i64 st = ((c.u1 - c.u0) + 3) & ~(i64)3; st < P.L; st += 4)
+    if (MODE >= 2)   // a short (last) chain marks the rest of its log column as "no entry"
+      for (i64 st = ((c.u1 - c.u0) + 3) & ~(i64)3; st < P.L; st += 4) {
         ((uint4 *)P.log)[(st >> 2) * P.K + c.k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (MODE == 3) P.log_hi[(st >> 2) * P.K + c.k] = 0xFFFFFFFFu;
+      }
     P.fin[c.k] = c.i;
   }
   if (CHECK_OVF && ovf) *P.ovf_flag = 1;
@@ -657,14 +671,19 @@ static void launch_build(const u8 *d_bwt, i64 m, const u8 *d_code, u32 *seg_cnt,
                      r->nseg, CNT, group_sum, ngroups);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum, ngroups, CNT);
   hipLaunchKernelGGL((rank_fill_kernel<CNT, B>), dim3((unsigned)r->nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, d_code, seg_cnt,
-                     group_sum, r->d_blocks, r->nblk);
+                     group_sum, r->d_blocks, r->nblk, r->sb_shift);
 }
 
 // Symbol-major layout (rank_sm.hpp).  *fell_back = true: not applicable / did not fit / overflow
 // pool exhausted -- the caller builds a block layout instead.
 static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double budget_bytes, bool allow_list8, bool *fell_back, bool *list8_failed) {
   *fell_back = true;
-  if (m >= 0xFFFFFFFFll) return 0;
+  // counts inside the entries are relative to superblocks of 2^31 positions (LIST8 keeps bit 31 of the count as
+  // its "dense bucket" flag); PSG_SM_SB_SHIFT makes them small so that tests run several superblocks
+  int sb_shift = 31;
+  if (const char *e = getenv("PSG_SM_SB_SHIFT")) { int v = atoi(e); if (v >= 12 && v <= 31) sb_shift = v; }
+  const int nsb = (int)(((m - 1) >> sb_shift) + 1);
+  if (nsb > 64) return 0;   // LDS table of the pass: 2 KiB per superblock
   // per-symbol mode: BITMAP (bucket 64) when a 256-bucket would hold > 3 occurrences on average; the other
   // symbols get 8-byte LIST8 entries (4 positions inline) if every one of them averages <= 1.5 per bucket
   // -- a byte-uniform text: 8 instead of 16 bytes of structure per symbol -- else 16-byte LIST entries
@@ -697,7 +716,7 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   const u32 pool_cap = (u32)std::min<double>(4.0e9, std::max<double>(1024.0, (double)m / 512.0 + (list8 ? 2.0 * dense8 + 65536.0 : 0.0)));
   if ((double)entries_bytes + 32.0 * pool_cap > budget_bytes) return 0;
   const i64 nseg = cdiv(m, SM_SEG), ngroups = cdiv(nseg, GROUP_SEGS);
-  DevBuf code_d, seg_cnt, group_sum, t2_d, misc;
+  DevBuf code_d, seg_cnt, group_sum, t2_d, misc, sb_d;
   int rc;
   u8 ident[256];
   for (int c = 0; c < 256; ++c) ident[c] = (u8)c;
@@ -705,17 +724,19 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   if (psg::pool_alloc((void **)&entries, (size_t)entries_bytes + 64) != hipSuccess) { (void)hipGetLastError(); return 0; }
   if (psg::pool_alloc((void **)&pool, (size_t)pool_cap * 32) != hipSuccess) { (void)hipGetLastError(); psg::pool_free(entries); return 0; }
   auto fail = [&](int code) { psg::pool_free(entries); psg::pool_free(pool); return code; };
-  if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(nseg * 256 * 4)) || (rc = group_sum.alloc(ngroups * 256 * 8)) || (rc = t2_d.alloc(256 * 8)) || (rc = misc.alloc(8)))
+  if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(nseg * 256 * 4)) || (rc = group_sum.alloc(ngroups * 256 * 8)) || (rc = t2_d.alloc(256 * 8)) || (rc = misc.alloc(8)) ||
+      (rc = sb_d.alloc((i64)nsb * 256 * 8)))
     return fail(rc);
   if ((rc = psg::copy_h2d(code_d.p, ident, 256)) || (rc = psg::copy_h2d(t2_d.p, t2, sizeof t2))) return fail(rc);
   if (hipMemsetAsync(misc.p, 0, 8, stream()) != hipSuccess) { set_error("sm_build: memset failed"); return fail(PSG_EDEVICE); }
   hipLaunchKernelGGL((seg_hist_kernel<256, 64>), dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>());
   hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * 256, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt.as<u32>(), nseg, 256, group_sum.as<u64>(), ngroups);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
+  hipLaunchKernelGGL(sm_sb_base_kernel, dim3((unsigned)nsb), dim3(256), 0, stream(), seg_cnt.as<u32>(), group_sum.as<u64>(), sb_shift - 12, sb_d.as<u64>());
   if (list8) hipLaunchKernelGGL(sm_fill_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
+                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_shift - 12);
   else hipLaunchKernelGGL(sm_fill_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1));
+                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_shift - 12);
   u32 st[2] = {0, 0};
   hipError_t e4 = hipGetLastError();
   if (e4 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4)); return fail(PSG_EDEVICE); }
@@ -725,10 +746,11 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
     *list8_failed = list8;
     return 0;
   }
-  r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = 1;
+  r->h_sb.assign((size_t)nsb * 256, 0);
+  if ((rc = psg::copy_d2h(r->h_sb.data(), sb_d.p, (size_t)nsb * 256 * 8))) return fail(rc);
+  r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = nsb; r->sb_shift = sb_shift;
   r->d_blocks = entries; r->d_aux = pool; r->blocks_bytes = entries_bytes + (i64)pool_cap * 32;
   for (int c = 0; c < 256; ++c) { r->t2[c] = t2[c]; r->code[c] = (u8)c; }
-  r->h_sb.assign(1, 0);
   *fell_back = false;
   return 0;
 }
@@ -802,7 +824,10 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   r->stride = 4 * r->cnt + r->B;
   r->nblk = cdiv(m, r->B);
   r->nseg = cdiv(r->nblk, SEG_BLOCKS);
-  r->nsb = (int)(((r->nblk - 1) >> SB_SHIFT) + 1);
+  r->sb_shift = SB_SHIFT_DEFAULT;   // superblocks start on scan-group boundaries: >= log2(SEG_BLOCKS * GROUP_SEGS) = 14
+  if (const char *e = getenv("PSG_BLOCK_SB_SHIFT")) { int v = atoi(e); if (v >= 14 && v <= 30) r->sb_shift = v; }
+  r->nsb = (int)(((r->nblk - 1) >> r->sb_shift) + 1);
+  if (r->nsb > 64) { delete r; set_error("psg_rank_build: too many superblocks for the LDS table"); return PSG_EINVAL; }
   i64 ngroups = cdiv(r->nseg, GROUP_SEGS);
   r->blocks_bytes = r->nblk * (i64)r->stride;
   int rc = 0;
@@ -810,7 +835,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   hipError_t e = psg::pool_alloc((void **)&r->d_blocks, (size_t)r->blocks_bytes + 64);   // +64: the upper-part read of the last block may run 16 B over
   if (e != hipSuccess) { set_error(std::string("rank blocks hipMalloc ") + std::to_string(r->blocks_bytes) + ": " + hipGetErrorString(e)); delete r; return PSG_ENOMEM; }
   if ((rc = code_d.alloc(256)) || (rc = seg_cnt.alloc(r->nseg * r->cnt * 4)) || (rc = group_sum.alloc(ngroups * r->cnt * 8))) { psg_rank_free(r); return rc; }
-  if (int rc_ = psg::copy_h2d(code_d.p, r->code, (size_t)(256))) return rc_;
+  if (int rc_ = psg::copy_h2d(code_d.p, r->code, (size_t)(256))) { psg_rank_free(r); return rc_; }
   if (r->cnt == 4) launch_build<4, 48>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
   else if (r->cnt == 16) launch_build<16, 64>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
   else if (r->B == 32) launch_build<256, 32>(d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>(), group_sum.as<u64>(), r, ngroups);
@@ -821,8 +846,8 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
   // superblock bases = group bases at the superblock starts
   r->h_sb.assign((size_t)r->nsb * r->cnt, 0);
   for (int s = 0; s < r->nsb; ++s) {
-    i64 g = (((i64)s << SB_SHIFT) / SEG_BLOCKS) / GROUP_SEGS;
-    if (int rc_ = psg::copy_d2h(&r->h_sb[(size_t)s * r->cnt], group_sum.as<u64>() + g * r->cnt, (size_t)((size_t)r->cnt * 8))) return rc_;
+    i64 g = (((i64)s << r->sb_shift) / SEG_BLOCKS) / GROUP_SEGS;
+    if (int rc_ = psg::copy_d2h(&r->h_sb[(size_t)s * r->cnt], group_sum.as<u64>() + g * r->cnt, (size_t)((size_t)r->cnt * 8))) { psg_rank_free(r); return rc_; }
   }
   tm.stop();
   PSG_HIP(psg::sync_stream());
@@ -850,7 +875,7 @@ static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &t
   for (int s = 0; s < r->nsb; ++s)
     for (int c = 0; c < 256; ++c) {
       u8 cd = r->code[c];
-      u64 base = (cd == 0xFF || r->cnt == 0) ? 0 : r->h_sb[(size_t)s * r->cnt + cd];
+      u64 base = r->cnt == 0 ? r->h_sb[(size_t)s * 256 + c] : (cd == 0xFF ? 0 : r->h_sb[(size_t)s * r->cnt + cd]);
       h[(size_t)s * 256 + c] = ((u64)(Cadd ? Cadd[c] : 0) + base) | ((u64)cd << CODE_SHIFT);
     }
   for (int c = 0; c < 256; ++c) { t[c] = (u64)r->count[c]; t[256 + c] = r->t2[c]; }
@@ -864,7 +889,7 @@ static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &t
 
 template <int CNT, int B>
 static void launch_query(const psg_rank *r, const u64 *T1, const u64 *tot, const i64 *qi, const u8 *qc, i64 nq, i64 *out) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((rank_query_kernel<CNT, B>), dim3((unsigned)cdiv(nq, PSG_WG)), dim3(PSG_WG), lds, stream(), R, T1, tot,
                      r->nsb, qi, qc, nq, out);
@@ -882,7 +907,7 @@ extern "C" int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uin
 }
 
 template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams P) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
 }
@@ -894,7 +919,7 @@ static int chains_per_lane(const psg_rank *r) {
   return 1;   // measured (MI355X, 4 GiB bench): 2 chains/lane at 4 waves/SIMD == 1 chain/lane at 8 waves/SIMD
 }
 template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode, int cpl) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   dim3 grid((unsigned)cdiv(cdiv(P.nchains, cpl), PSG_WG));
 #define PSG_LAUNCH(MODE_)                                                                                          \
@@ -902,7 +927,8 @@ template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamPar
     if (cpl == 2) hipLaunchKernelGGL((stream_kernel<CNT, B, MODE_, 2>), grid, dim3(PSG_WG), lds, stream(), R, P);  \
     else hipLaunchKernelGGL((stream_kernel<CNT, B, MODE_, 1>), grid, dim3(PSG_WG), lds, stream(), R, P);           \
   } while (0)
-  if (mode == 2) PSG_LAUNCH(2);
+  if (mode == 3) PSG_LAUNCH(3);
+  else if (mode == 2) PSG_LAUNCH(2);
   else if (mode == 1) PSG_LAUNCH(1);
   else PSG_LAUNCH(0);
 #undef PSG_LAUNCH
@@ -917,7 +943,8 @@ template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mod
     if (cpl == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, lds);  \
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, lds);           \
   } while (0)
-  if (mode == 2) PSG_OCC(2);
+  if (mode == 3) PSG_OCC(3);
+  else if (mode == 2) PSG_OCC(2);
   else if (mode == 1) PSG_OCC(1);
   else PSG_OCC(0);
 #undef PSG_OCC
@@ -1025,10 +1052,11 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
     if (e && !strcmp(e, "atomic")) want_log = false;
     if (e && !strcmp(e, "ovf")) { want_log = false; mode = 1; }   // tests: force the overflow-checking atomic kernel
-    if (want_log && r->m < 0xFFFFFFFFll && mode == 0) mode = 2;
-    if (log_out) mode = 2;   // the caller wants the log itself
+    const bool wide = r->m >= 0xFFFFFFFFll || getenv("PSG_LOG_WIDE") != nullptr;   // ranks need more than 32 bits (tests: forced)
+    if (want_log && mode == 0) mode = wide ? 3 : 2;
+    if (log_out) mode = 2;   // the caller wants the log itself (32-bit ranks: checked by psg_stream_gap_log)
   }
-  if (fresh && mode != 2) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));   // the atomics need zeroes; the histogram overwrites
+  if (fresh && mode < 2) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));   // the atomics need zeroes; the histogram overwrites
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
   // pass time: every chain has the same length)
   const int cpl = chains_per_lane(r);
@@ -1077,11 +1105,12 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   }
   st.unresolved = nun;
   if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
-  DevBuf log_d;
-  if (mode == 2) {
+  DevBuf log_d, loghi_d;
+  if (mode >= 2) {
     if ((rc = log_d.alloc(K * L * 4))) return rc;   // every entry is written by its chain (0xFFFFFFFF = no entry)
+    if (mode == 3 && (rc = loghi_d.alloc(K * L))) return rc;
   }
-  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K};
+  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K, loghi_d.as<u32>()};
   double kms = 0;
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
@@ -1143,6 +1172,8 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   } else if (mode == 2) {
     if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh))) return rc;
     log_d.alloc(16);   // give the log back to the pool before returning
+  } else if (mode == 3) {
+    if ((rc = psg::gap_hist_from_wide_log(log_d, loghi_d, K * L, r->m, d_gap, &hist_ms, fresh))) return rc;
   }
   st.hist_ms = hist_ms;
   int ovf = 0;

@@ -336,7 +336,10 @@ int psg_init(int device) {
 }
 
 int psg_set_stream(void *s) {
-  if (g_own_stream && g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); }
+  // the allocator hands freed blocks out again at once because everything runs on ONE stream: work still in
+  // flight on the outgoing stream (ours or the caller's) must drain before the next stream may reuse its buffers
+  if (g_stream) (void)hipStreamSynchronize(g_stream);
+  if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
   g_own_stream = false;
   g_stream = (hipStream_t)s;
   if (!s) {

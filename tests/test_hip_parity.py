@@ -202,6 +202,110 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+# ------------------------------------------------------------------ blocks of >= 2^32 symbols: the code they run, at oracle sizes
+# A block of >= 2^32 - 1 symbols runs (a) several superblocks in the rank structure (counts relative to the
+# superblock, bases in the LDS table of the pass) and (b) the two-plane rank log + slab split before the
+# histogram.  Both sizes are test parameters (PSG_SM_SB_SHIFT / PSG_BLOCK_SB_SHIFT / PSG_LOG_SLAB_SHIFT /
+# PSG_LOG_WIDE) so that the same code runs here against the oracle; tests/test_scale_gpu.py runs a real 2^32+ block.
+@pytest.mark.parametrize("sigma,layout", [(255, 0), (255, 1), (4, 0), (12, 0), ("runs", 1), ("skew", 1), (1, 0)])
+@pytest.mark.parametrize("m", [4097, 100003, 300007])
+def test_rank_query_many_superblocks_symbol_major(A, monkeypatch, sigma, layout, m):
+    monkeypatch.setenv("PSG_SM_SB_SHIFT", "12" if m < 200000 else "13")     # 4096 (8192) positions per superblock: up to 37 superblocks
+    rng = np.random.default_rng(m + 11)
+    if sigma == "runs":
+        bwt = np.repeat(rng.integers(0, 200, m // 20 + 1, dtype=np.uint8), rng.integers(1, 60, m // 20 + 1))[:m]
+        if len(bwt) < m:
+            bwt = np.concatenate([bwt, np.zeros(m - len(bwt), np.uint8)])
+    elif sigma == "skew":
+        bwt = np.where(rng.random(m) < 0.8, rng.integers(0, 3, m), rng.integers(3, 250, m)).astype(np.uint8)
+    else:
+        bwt = rng.integers(0, sigma, m, dtype=np.uint8)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m, layout)
+    assert r.device_bytes() > 0
+    rk = orc.Rank(bwt)
+    assert np.array_equal(r.counts, rk.counts())
+    qi = np.concatenate([rng.integers(-3, m + 4, 6000), np.arange(4090, 4100), np.arange(8186, 8200), [m - 1, m, m + 1]]).astype(np.int64)
+    qc = rng.integers(0, 256, len(qi)).astype(np.uint8)
+    qc[::2] = bwt[rng.integers(0, m, len(qc[::2]))]
+    got = r.query(qi, qc)
+    want = np.array([rk.rank(i, c) for i, c in zip(qi, qc)], np.int64)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("layout", [32, 64, 128, 256, -64, 48])
+def test_rank_query_many_superblocks_blocks(A, monkeypatch, layout):
+    """interleaved-block layouts with several superblocks (T1[sb*256+c], superblock-relative counters)"""
+    monkeypatch.setenv("PSG_BLOCK_SB_SHIFT", "14")      # 2^14 blocks per superblock (the smallest the build allows)
+    B = abs(layout)
+    m = 3 * (1 << 14) * B + 12345                        # four superblocks
+    rng = np.random.default_rng(layout + 100)
+    bwt = rng.integers(0, 4 if layout == 48 else 255, m, dtype=np.uint8)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m, layout)
+    rk = orc.Rank(bwt)
+    assert np.array_equal(r.counts, rk.counts())
+    edges = np.concatenate([np.arange(k * (1 << 14) * B - 3, k * (1 << 14) * B + 4) for k in (1, 2, 3)])
+    qi = np.concatenate([rng.integers(-3, m + 4, 6000), edges, [m - 1, m, m + 1]]).astype(np.int64)
+    qc = rng.integers(0, 256, len(qi)).astype(np.uint8)
+    qc[::2] = bwt[rng.integers(0, m, len(qc[::2]))]
+    got = r.query(qi, qc)
+    want = np.array([rk.rank(i, c) for i, c in zip(qi, qc)], np.int64)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["rand255", "sig4z", "dna", "alla", "fib"])
+@pytest.mark.parametrize("fresh", [False, True])
+def test_stream_gap_wide_log_and_superblocks(A, monkeypatch, kind, fresh):
+    """the whole pass as a block of >= 2^32 symbols runs it: superblock-relative rank entries, 40-bit rank log in
+    two planes, slab split, per-slab histograms -- against the oracle."""
+    monkeypatch.setenv("PSG_SM_SB_SHIFT", "13")
+    monkeypatch.setenv("PSG_LOG_WIDE", "1")
+    monkeypatch.setenv("PSG_LOG_SLAB_SHIFT", "13")      # slabs of 8192 counters
+    monkeypatch.setenv("PSG_GAP_MODE", "log")
+    n = 200000 if kind in ("rand255", "sig4z", "dna") else 60000
+    t = make_text(kind, n, 31)
+    b, e = 777, 777 + n // 3
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m = e - b
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    T = n - e
+    d_gap = A.upload(np.full(m + 1, 0xDEADBEEF if fresh else 3, np.uint32))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300, fresh_gap=fresh)
+    assert fin == want_fin and st.hist_ms > 0
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap + (0 if fresh else 3))
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
+def test_stream_gap_wide_log_chunked_block_layout(A, monkeypatch):
+    """wide log + chunked pass + interleaved-block rank with several superblocks (the fallback layout of a huge block)"""
+    monkeypatch.setenv("PSG_BLOCK_SB_SHIFT", "14")
+    monkeypatch.setenv("PSG_RANK_LAYOUT", "block")
+    monkeypatch.setenv("PSG_LOG_WIDE", "1")
+    monkeypatch.setenv("PSG_LOG_SLAB_SHIFT", "16")
+    monkeypatch.setenv("PSG_GAP_MODE", "log")
+    monkeypatch.setenv("PSG_PASS_CHUNK", "65536")
+    import psascan_amd.extras as X
+    mid, T = (1 << 14) * 32 * 2 + 999, 150_001           # B = 32 -> three superblocks
+    n = mid + T
+    rng = np.random.default_rng(77)
+    t = rng.integers(3, 255, n, dtype=np.uint8)
+    t[mid - 1] = 0
+    d_text = A.upload(t, pad_to=16)
+    Lh = X.sort_halfblock(d_text, n, 0, mid, want_gt=False)
+    lbwt = A.download(Lh["bwt"], np.uint8, mid)
+    gt_in = np.zeros((T + 7) // 8 + 8, np.uint8)
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(lbwt), Lh["i0"], 0, t, mid, n, gt_in, 0)
+    r = A.rank_build(Lh["bwt"], mid, 32)
+    d_gap = A.zeros(4 * (mid + 2))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 4))
+    fin, st = A.stream_gap(r, Lh["i0"], 0, d_text.at(mid), T, A.upload(gt_in, pad_to=16), 0, d_gap, d_gtout, 0)
+    assert fin == want_fin and st.hist_ms > 0 and st.rounds >= 3
+    assert np.array_equal(A.download(d_gap, np.uint32, mid + 1).astype(np.uint64), want_gap)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
 def test_device_allocator_arena(A, gpu_lib):
     """psg_malloc/psg_free go through the arena of runtime.hip (best fit, split, coalesce for blocks >= 1 MiB,
     size classes below): live blocks never overlap, whatever the order of frees and the mix of sizes."""

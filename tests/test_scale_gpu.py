@@ -29,6 +29,28 @@ def test_multiblock_properties(gpu_lib, mode, sigma, mib, block_mib):
     assert text[first] == text.min()
 
 
+def test_block_of_more_than_2_pow_32_symbols(gpu_lib):
+    """A real block of >= 2^32 symbols on the fast path (reference: psascan.hpp:117-125 has no block size limit,
+    rank.hpp:566-568): 6 GiB of random bytes, block 0 = [0, 4.25 GiB) in two halves of 2.125 GiB, so that pass B
+    streams a 1.75 Gi tail through a rank structure over m = 4.25 Gi symbols (three superblocks of 2^31
+    positions, 40-bit rank log in two planes, three slabs of gap counters).  Checked by the library's own
+    invariants on the way (sum(gap) == tail length, chain hand-over ranks) and the .sa5 properties."""
+    from psascan_amd import api, extras, pipeline
+    n = (6 << 30) + 12345
+    blk = (17 << 28)                                   # 4.25 GiB
+    d_text = extras.gen_text(n, 0, 0, seed=41)
+    text = api.download(d_text, np.uint8, n)
+    sorter = extras.DeviceSorter(d_text, n)
+    stats = []
+    d_out = pipeline.construct_sa5(text, blk, 1 << 40, sorter, stats=stats, d_text=d_text, return_device=True)
+    bad, s = extras.check_sa5(d_text, n, d_out, n, samples=1 << 20, seed=5)
+    assert bad == 0
+    assert s == (n * (n - 1) // 2) % (1 << 64)
+    pb = [p for p in stats if p[0] == "B"]
+    assert len(pb) == 1 and pb[0][2] - pb[0][1] == blk and pb[0][3].hist_ms > 0
+    print("pass B over a 4.25 Gi block:", pb[0][3].total_ms, "ms, kernel", pb[0][3].kernel_ms, "hist", pb[0][3].hist_ms)
+
+
 def english_like(n, seed=1, nwords=4096):
     """Zipfian words over a skewed 26-letter alphabet: repeats of tens of bytes, sigma = 28."""
     rng = np.random.default_rng(seed)
