@@ -51,6 +51,11 @@ int psg_h2d(void *d_dst, const void *h_src, int64_t bytes);
 int psg_d2h(void *h_dst, const void *d_src, int64_t bytes);
 int psg_d2d(void *d_dst, const void *d_src, int64_t bytes);
 int psg_sync(void);
+/* page-locked host memory: psg_h2d / psg_d2h / psg_merge_stream copy from / to it without a staging step */
+int psg_host_alloc(void **h_ptr, int64_t bytes);
+int psg_host_free(void *h_ptr);
+/* device memory: bytes handed out by psg_malloc right now / the highest value so far / held from the driver */
+int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved);
 /* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int psg_set_stream(void *hip_stream);
 
@@ -163,6 +168,43 @@ typedef struct psg_merge_plan psg_merge_plan_t;
 int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out);
 int psg_merge_run(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint8_t *d_out_sa5);
 void psg_merge_plan_free(psg_merge_plan_t *plan);
+
+/* ---- merge<T> with the partial suffix arrays in HOST memory.  The reference keeps every partial SA in part files
+ *      (io/distributed_file.hpp:58-67) and streams them back during the merge (merge.hpp:72-81, 143; parts
+ *      deleted as consumed, distributed_file.hpp:159-171); here they stay where the host sorter left them and
+ *      are staged through pinned buffers slice by slice: slice k+1 is copied in while slice k is merged and
+ *      slice k-1 is copied out / handed to the sink.  The merge bitvectors stay in HBM.
+ *  h_psa_lo/h_psa_hi  host arrays (pageable or pinned), positions relative to beg
+ *  sink               called in output order with `n_entries` packed uint40 values (5 bytes each, pinned host
+ *                     memory, valid until it returns); non-zero return aborts the merge (PSG_ECHECK).
+ *                     NULL: the output is produced in HBM and dropped (use with `check`).
+ *  check              optional property check of every slice on the device: sum of all entries (mod 2^64; a
+ *                     permutation of 0..n-1 gives n(n-1)/2) and sampled adjacent pairs out of suffix order.       */
+typedef struct {
+  int64_t beg, size;
+  const uint32_t *h_psa_lo;
+  const uint8_t *h_psa_hi;   /* may be NULL */
+  const uint32_t *d_mbv;     /* device; size + (sizes of all later half-blocks) bits; NULL for the last */
+} psg_hb_host_desc;
+typedef int (*psg_sink_fn)(void *ctx, const uint8_t *h_sa5, int64_t first_entry, int64_t n_entries);
+typedef struct {
+  const uint8_t *d_text;     /* the whole text on the device */
+  int64_t n;
+  int64_t samples_per_slice;
+  uint64_t seed;
+  uint64_t sum;              /* out */
+  int64_t bad_pairs;         /* out */
+} psg_merge_check;
+typedef struct {
+  int64_t slices;
+  double total_ms;           /* wall time of the call                                   */
+  double kernel_ms;          /* merge kernels (HIP events)                              */
+  double stage_ms;           /* host time spent copying PSA pieces into pinned buffers  */
+  double sink_ms;            /* host time spent inside the sink                         */
+  int64_t h2d_bytes, d2h_bytes;
+} psg_merge_stream_stats;
+int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slice_entries, psg_merge_check *check,
+                     psg_sink_fn sink, void *sink_ctx, psg_merge_stream_stats *stats);
 
 /* ---- multi-GPU building blocks: one pass sharded over the TAIL (the reference's own parallel
  *      axis, compute_gap.hpp:68-69,114-124), the gap array sharded by index range.  Each rank

@@ -21,6 +21,22 @@ class HbDescC(C.Structure):
     _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p)]
 
 
+class HbHostDescC(C.Structure):
+    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("h_psa_lo", C.c_void_p), ("h_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p)]
+
+
+class MergeCheckC(C.Structure):
+    _fields_ = [("d_text", C.c_void_p), ("n", C.c_int64), ("samples_per_slice", C.c_int64), ("seed", C.c_uint64),
+                ("sum", C.c_uint64), ("bad_pairs", C.c_int64)]
+
+
+class MergeStreamStatsC(C.Structure):
+    _fields_ = [("slices", C.c_int64), ("total_ms", C.c_double), ("kernel_ms", C.c_double), ("stage_ms", C.c_double),
+                ("sink_ms", C.c_double), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64)]
+
+
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
+
 # every symbol include/psascan_amd.h declares: name -> (restype, argtypes)
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
 SIGNATURES = {
@@ -35,6 +51,9 @@ SIGNATURES = {
     "psg_d2h": (_int, [_vp, _vp, _i64]),
     "psg_d2d": (_int, [_vp, _vp, _i64]),
     "psg_sync": (_int, []),
+    "psg_host_alloc": (_int, [C.POINTER(_vp), _i64]),
+    "psg_host_free": (_int, [_vp]),
+    "psg_mem_stats": (_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "psg_set_stream": (_int, [_vp]),
     "psg_rank_build": (_int, [_vp, _i64, _int, C.POINTER(_vp)]),
     "psg_rank_counts": (_int, [_vp, C.POINTER(_i64)]),
@@ -58,6 +77,7 @@ SIGNATURES = {
     "psg_merge_plan_create": (_int, [C.POINTER(HbDescC), _int, C.POINTER(_vp)]),
     "psg_merge_run": (_int, [_vp, _i64, _i64, _vp]),
     "psg_merge_plan_free": (None, [_vp]),
+    "psg_merge_stream": (_int, [C.POINTER(HbHostDescC), _int, _i64, C.POINTER(MergeCheckC), SINK_FN, _vp, C.POINTER(MergeStreamStatsC)]),
     "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
     "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "psg_last_kernel_ms": (C.c_double, []),

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import HbDescC, StreamStatsC, check, lib
+from ._lib import HbDescC, HbHostDescC, MergeCheckC, MergeStreamStatsC, SINK_FN, StreamStatsC, check, lib
 
 
 class DeviceBuffer:
@@ -208,6 +208,79 @@ def merge_half_blocks(half_blocks, d_out=None):
     plan.run(0, plan.n, d_out)
     plan.free()
     return d_out
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (psg_host_alloc): DMA source / target without a staging copy."""
+
+    def __init__(self, count, dtype):
+        self.dtype = np.dtype(dtype)
+        self.count = int(count)
+        p = C.c_void_p()
+        check(lib().psg_host_alloc(C.byref(p), max(16, self.count * self.dtype.itemsize)))
+        self.ptr = p.value
+        buf = (C.c_char * (self.count * self.dtype.itemsize)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, self.dtype, self.count)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().psg_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def mem_stats():
+    """(bytes in use, peak bytes in use, bytes reserved from the driver) of the library's device allocator."""
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    check(lib().psg_mem_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, samples_per_slice=0, seed=1):
+    """merge<T> with the partial SAs in host memory (numpy arrays / PinnedArray.array under "psa_lo", optional
+    "psa_hi"), merge bitvectors on the device.  sink(bytes_view: np.uint8, first_entry, n_entries) is called in
+    output order.  Returns (stats, check) with check = (sum, bad_pairs) or None."""
+    H = len(half_blocks)
+    arr = (HbHostDescC * H)()
+    keep = []
+    for k, hb in enumerate(half_blocks):
+        lo = np.ascontiguousarray(hb["psa_lo"], np.uint32) if not isinstance(hb["psa_lo"], np.ndarray) or hb["psa_lo"].dtype != np.uint32 else hb["psa_lo"]
+        keep.append(lo)
+        arr[k].beg, arr[k].size = hb["beg"], hb["size"]
+        arr[k].h_psa_lo = lo.ctypes.data
+        hi = hb.get("psa_hi")
+        if hi is not None:
+            hi = np.ascontiguousarray(hi, np.uint8)
+            keep.append(hi)
+            arr[k].h_psa_hi = hi.ctypes.data
+        arr[k].d_mbv = _ptr(hb.get("mbv"))
+    err = []
+
+    def _sink(ctx, ptr, first, cnt):
+        try:
+            view = np.frombuffer((C.c_char * (5 * cnt)).from_address(ptr), np.uint8, 5 * cnt)
+            sink(view, first, cnt)
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            err.append(e)
+            return 1
+
+    cb = SINK_FN(_sink) if sink is not None else C.cast(None, SINK_FN)
+    chk = None
+    if check_text is not None:
+        chk = MergeCheckC(_ptr(check_text), n, samples_per_slice, seed, 0, 0)
+    st = MergeStreamStatsC()
+    rc = lib().psg_merge_stream(arr, H, slice_entries, C.byref(chk) if chk is not None else None, cb, None, C.byref(st))
+    if err:
+        raise err[0]
+    check(rc)
+    return st, ((chk.sum, chk.bad_pairs) if chk is not None else None)
 
 
 def bitcopy(d_dst, dst_bit, d_src, src_bit, nbits):

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <thread>
 #include <vector>
 
 using namespace psg;
@@ -718,13 +719,13 @@ extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
   delete p;
 }
 
-extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out) {
-  PSG_REQUIRE(hbs && H >= 1 && out, "psg_merge_plan_create");
+// need_psa = false: the partial SAs are not on the device (psg_merge_stream); lo/hi of the levels stay null
+static int plan_build(const psg_hb_desc *hbs, int H, bool need_psa, psg_merge_plan_t **out) {
   psg_merge_plan *p = new psg_merge_plan();
   p->H = H;
   std::vector<i64> nh(H + 1, 0);
   for (int h = H - 1; h >= 0; --h) {
-    if (hbs[h].size < 1 || !hbs[h].d_psa_lo || (h + 1 < H && !hbs[h].d_mbv) || (h > 0 && hbs[h].beg < hbs[h - 1].beg)) {
+    if (hbs[h].size < 1 || (need_psa && !hbs[h].d_psa_lo) || (h + 1 < H && !hbs[h].d_mbv) || (h > 0 && hbs[h].beg < hbs[h - 1].beg)) {
       psg_merge_plan_free(p); set_error("psg_merge_plan_create: bad half-block descriptor " + std::to_string(h)); return PSG_EINVAL;
     }
     nh[h] = nh[h + 1] + hbs[h].size;
@@ -762,6 +763,26 @@ extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_pl
   return 0;
 }
 
+extern "C" int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out) {
+  PSG_REQUIRE(hbs && H >= 1 && out, "psg_merge_plan_create");
+  return plan_build(hbs, H, true, out);
+}
+
+// enqueue the merge kernel for the output range [out_begin, out_begin + out_count); lv/L0/L1 carry the PSA pointers
+static int merge_launch(int H, const MergeLevel *d_levels, const MergeLevel &L0, const MergeLevel &L1, bool any_hi,
+                        i64 out_begin, i64 out_count, u8 *d_out) {
+  const unsigned grid = (unsigned)cdiv(out_count, MT);
+  if (H == 2 && !getenv("PSG_MERGE_GENERAL")) {   // one block: the two-way kernel
+    if (any_hi) hipLaunchKernelGGL(merge2_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
+    else hipLaunchKernelGGL(merge2_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
+  } else {
+    if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out);
+    else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out);
+  }
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64_t out_count, uint8_t *d_out) {
   PSG_REQUIRE(p && d_out && out_begin >= 0 && out_count >= 0 && out_begin + out_count <= p->n, "psg_merge_run: range");
   PSG_REQUIRE(((uintptr_t)d_out & 3) == 0, "psg_merge_run: output must be 4-byte aligned");
@@ -769,22 +790,202 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
   EventTimer tm; tm.start();
   bool any_hi = false;
   for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
-  if (p->H == 2 && !getenv("PSG_MERGE_GENERAL")) {   // one block: the two-way kernel
-    const unsigned g2 = (unsigned)cdiv(out_count, MT);
-    if (any_hi) hipLaunchKernelGGL(merge2_kernel<true>, dim3(g2), dim3(PSG_WG), 0, stream(), p->levels[0], p->levels[1], out_begin, out_count, d_out);
-    else hipLaunchKernelGGL(merge2_kernel<false>, dim3(g2), dim3(PSG_WG), 0, stream(), p->levels[0], p->levels[1], out_begin, out_count, d_out);
-    PSG_HIP(hipGetLastError());
-    tm.stop();
-    PSG_HIP(psg::sync_stream());
-    note_kernel_ms(tm.ms());
-    return 0;
-  }
-  const unsigned grid = (unsigned)cdiv(out_count, MT);
-  if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
-  else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, d_out);
-  PSG_HIP(hipGetLastError());
+  if (int rc = merge_launch(p->H, p->d_levels, p->levels[0], p->levels[p->H > 1 ? 1 : 0], any_hi, out_begin, out_count, d_out)) return rc;
   tm.stop();
   PSG_HIP(psg::sync_stream());
   note_kernel_ms(tm.ms());
+  return 0;
+}
+
+// =======================================================================================
+// K7 with the partial suffix arrays in host memory (psg_merge_stream)
+// =======================================================================================
+// cur[b * H + h] = number of own elements of half-block h among the first xs[b] output slots: the walk of
+// merge_kernel for ONE position (rank1 of every level from its samples + a partial popcount).  Block b, 128 threads.
+__global__ __launch_bounds__(128) void merge_cursor_kernel(const MergeLevel *lv, int H, const i64 *xs, i64 *cur) {
+  __shared__ u32 red[2];
+  i64 q = xs[blockIdx.x];
+  for (int h = 0; h < H; ++h) {
+    const MergeLevel L = lv[h];
+    if (h == H - 1) { if (threadIdx.x == 0) cur[(i64)blockIdx.x * H + h] = q; break; }
+    i64 ones;
+    if (q >= L.nbits) ones = L.nbits - L.size;       // everything: all elements of the later half-blocks
+    else {
+      const i64 g = q >> 12, gbase = g << 12;
+      u32 part = 0;
+      const i64 wb = gbase + (i64)threadIdx.x * 32;
+      if (wb < q) { u32 w = gload(L.mbv + (wb >> 5)); const i64 nb = q - wb; if (nb < 32) w &= (1u << nb) - 1u; part = __popc(w); }
+      const u32 inc = wave_incl_scan(part);
+      if (lane_id() == 63) red[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      ones = (i64)gload(L.samp + g) + red[0] + red[1];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) cur[(i64)blockIdx.x * H + h] = q - ones;
+    q = ones;
+  }
+}
+
+static bool host_ptr_is_pinned(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+static double wall_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+// copy `pieces` (dst, src, bytes) with a few helper threads (pageable -> pinned runs at 30 GiB/s on one core,
+// ~100 GiB/s on eight; the PCIe link takes 50 GiB/s)
+struct CopyPiece { char *dst; const char *src; size_t bytes; };
+static void parallel_memcpy(const std::vector<CopyPiece> &pieces) {
+  size_t total = 0;
+  for (auto &c : pieces) total += c.bytes;
+  const int nt = total < ((size_t)8 << 20) ? 1 : 8;
+  if (nt == 1) { for (auto &c : pieces) memcpy(c.dst, c.src, c.bytes); return; }
+  const size_t per = (total + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      size_t lo = per * t, hi = std::min(total, lo + per), off = 0;   // this thread copies bytes [lo, hi) of the concatenation
+      for (auto &c : pieces) {
+        const size_t a = std::max(lo, off), b = std::min(hi, off + c.bytes);
+        if (a < b) memcpy(c.dst + (a - off), c.src + (a - off), b - a);
+        off += c.bytes;
+      }
+    });
+  for (auto &t : th) t.join();
+}
+
+extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slice_entries, psg_merge_check *check,
+                                psg_sink_fn sink, void *sink_ctx, psg_merge_stream_stats *stats) {
+  PSG_REQUIRE(hbs && H >= 1 && slice_entries >= 1, "psg_merge_stream");
+  PSG_REQUIRE(!check || (check->d_text && check->n > 0), "psg_merge_stream: check needs the text on the device");
+  const double w0 = wall_ms();
+  slice_entries = cdiv(slice_entries, MT) * MT;        // whole merge tiles: keeps every slice's output 16-byte aligned
+  std::vector<psg_hb_desc> dd((size_t)H);
+  bool any_hi = false;
+  for (int h = 0; h < H; ++h) {
+    PSG_REQUIRE(hbs[h].h_psa_lo, "psg_merge_stream: partial suffix array missing");
+    dd[(size_t)h] = psg_hb_desc{hbs[h].beg, hbs[h].size, nullptr, nullptr, hbs[h].d_mbv};
+    any_hi |= hbs[h].h_psa_hi != nullptr;
+  }
+  psg_merge_plan *plan = nullptr;
+  if (int rc = plan_build(dd.data(), H, false, &plan)) return rc;
+  struct PlanGuard { psg_merge_plan *p; ~PlanGuard() { psg_merge_plan_free(p); } } plan_guard{plan};
+  const i64 n = plan->n, ns = cdiv(n, slice_entries);
+  psg_merge_stream_stats st = {};
+  st.slices = ns;
+  // ---- cursors of every half-block at every slice boundary
+  std::vector<i64> xs((size_t)ns + 1);
+  for (i64 k = 0; k <= ns; ++k) xs[(size_t)k] = std::min<i64>(n, k * slice_entries);
+  DevBuf xs_d, cur_d;
+  int rc;
+  if ((rc = xs_d.alloc((ns + 1) * 8)) || (rc = cur_d.alloc((ns + 1) * H * 8))) return rc;
+  if ((rc = psg::copy_h2d(xs_d.p, xs.data(), (size_t)(ns + 1) * 8))) return rc;
+  hipLaunchKernelGGL(merge_cursor_kernel, dim3((unsigned)(ns + 1)), dim3(128), 0, stream(), plan->d_levels, H, xs_d.as<i64>(), cur_d.as<i64>());
+  PSG_HIP(hipGetLastError());
+  std::vector<i64> cur((size_t)(ns + 1) * H);
+  if ((rc = psg::copy_d2h(cur.data(), cur_d.p, cur.size() * 8))) return rc;
+  for (int h = 0; h < H; ++h)
+    if (cur[(size_t)ns * H + h] != hbs[h].size || cur[(size_t)h] != 0) { set_error("psg_merge_stream: cursor check failed at half-block " + std::to_string(h)); return PSG_ECHECK; }
+  // ---- buffers: two slots each
+  const i64 lo_cap = slice_entries * 4 + (i64)H * 16, hi_cap = any_hi ? slice_entries + (i64)H * 16 : 0, in_cap = lo_cap + hi_cap;
+  const i64 out_cap = 5 * slice_entries + 16;
+  DevBuf din[2], dout[2], dlv[2], acc;
+  char *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  MergeLevel *pin_lv[2] = {nullptr, nullptr};
+  const bool direct = [&] { for (int h = 0; h < H; ++h) if (!host_ptr_is_pinned(hbs[h].h_psa_lo) || (hbs[h].h_psa_hi && !host_ptr_is_pinned(hbs[h].h_psa_hi))) return false; return true; }();
+  for (int s = 0; s < 2; ++s) {
+    if ((rc = din[s].alloc(in_cap)) || (rc = dout[s].alloc(out_cap)) || (rc = dlv[s].alloc((i64)sizeof(MergeLevel) * H))) return rc;
+    if (!direct) pin_in[s] = (char *)pinned_buf(8 + s, (size_t)in_cap);
+    if (sink) pin_out[s] = (char *)pinned_buf(10 + s, (size_t)out_cap);
+    if ((!direct && !pin_in[s]) || (sink && !pin_out[s])) { set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
+  }
+  pin_lv[0] = (MergeLevel *)pinned_buf(12, 2 * sizeof(MergeLevel) * (size_t)H);
+  if (!pin_lv[0]) { set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
+  pin_lv[1] = pin_lv[0] + H;
+  if (check) { if ((rc = acc.alloc(16))) return rc; PSG_HIP(hipMemsetAsync(acc.p, 0, 16, stream())); }
+  hipStream_t up = side_stream();
+  if (!up) { set_error("psg_merge_stream: cannot create the copy stream"); return PSG_EDEVICE; }
+  hipEvent_t ev_up[2] = {event_acquire(), event_acquire()}, ev_dn[2] = {event_acquire(), event_acquire()};
+  hipEvent_t ev_k0[2] = {event_acquire(), event_acquire()}, ev_k1[2] = {event_acquire(), event_acquire()};
+  struct EvGuard { hipEvent_t *a, *b, *c, *d; ~EvGuard() { for (int s = 0; s < 2; ++s) { event_release(a[s]); event_release(b[s]); event_release(c[s]); event_release(d[s]); } } } ev_guard{ev_up, ev_dn, ev_k0, ev_k1};
+  PSG_HIP(psg::sync_stream());   // cursor work and the memset are done before the copy stream starts
+  auto wait_event = [](hipEvent_t e) { hipError_t q; while ((q = hipEventQuery(e)) == hipErrorNotReady) { } return q; };
+  int result = 0;
+  for (i64 k = 0; k < ns + 2 && !result; ++k) {
+    if (k >= 2) {                                      // slice k-2 has left the device: hand it to the sink
+      const int s = (int)(k & 1);
+      if (wait_event(ev_dn[s]) != hipSuccess) { set_error("psg_merge_stream: device error"); result = PSG_EDEVICE; break; }
+      float f = 0;
+      (void)hipEventElapsedTime(&f, ev_k0[s], ev_k1[s]);
+      st.kernel_ms += f;
+      if (sink) {
+        const i64 x0 = xs[(size_t)k - 2], cnt = xs[(size_t)k - 1] - x0;
+        const double t0 = wall_ms();
+        if (sink(sink_ctx, (const uint8_t *)pin_out[s], x0, cnt) != 0) { set_error("psg_merge_stream: the sink reported an error"); result = PSG_ECHECK; break; }
+        st.sink_ms += wall_ms() - t0;
+      }
+    }
+    if (k >= ns) continue;
+    const int s = (int)(k & 1);
+    const i64 x0 = xs[(size_t)k], cnt = xs[(size_t)k + 1] - x0;
+    // ---- stage the PSA pieces of slice k: device layout = pieces back to back, each 16-byte aligned
+    const double t0 = wall_ms();
+    std::vector<CopyPiece> pieces;
+    i64 off = 0, offh = lo_cap;
+    for (int h = 0; h < H; ++h) {
+      const i64 c0 = cur[(size_t)k * H + h], c1 = cur[(size_t)(k + 1) * H + h], len = c1 - c0;
+      MergeLevel L = plan->levels[(size_t)h];
+      L.lo = (const u32 *)(din[s].as<char>() + off) - c0;          // absolute indices c0.. land inside the piece
+      L.hi = nullptr;
+      if (len > 0) {
+        if (direct) PSG_HIP(hipMemcpyAsync(din[s].as<char>() + off, hbs[h].h_psa_lo + c0, (size_t)len * 4, hipMemcpyHostToDevice, up));
+        else pieces.push_back({pin_in[s] + off, (const char *)(hbs[h].h_psa_lo + c0), (size_t)len * 4});
+        st.h2d_bytes += len * 4;
+      }
+      off += (len * 4 + 15) / 16 * 16;
+      if (any_hi) {
+        L.hi = (const u8 *)(din[s].as<char>() + offh) - c0;
+        if (len > 0) {
+          if (hbs[h].h_psa_hi) {
+            if (direct) PSG_HIP(hipMemcpyAsync(din[s].as<char>() + offh, hbs[h].h_psa_hi + c0, (size_t)len, hipMemcpyHostToDevice, up));
+            else pieces.push_back({pin_in[s] + offh, (const char *)(hbs[h].h_psa_hi + c0), (size_t)len});
+          } else if (direct) PSG_HIP(hipMemsetAsync(din[s].as<char>() + offh, 0, (size_t)len, up));
+          else memset(pin_in[s] + offh, 0, (size_t)len);
+          st.h2d_bytes += len;
+        }
+        offh += (len + 15) / 16 * 16;
+      }
+      pin_lv[s][h] = L;
+    }
+    if (!direct) {
+      parallel_memcpy(pieces);
+      PSG_HIP(hipMemcpyAsync(din[s].p, pin_in[s], (size_t)off, hipMemcpyHostToDevice, up));
+      if (any_hi) PSG_HIP(hipMemcpyAsync(din[s].as<char>() + lo_cap, pin_in[s] + lo_cap, (size_t)(offh - lo_cap), hipMemcpyHostToDevice, up));
+    }
+    PSG_HIP(hipEventRecord(ev_up[s], up));
+    st.stage_ms += wall_ms() - t0;
+    // ---- merge slice k behind its copy, check it, send it back
+    PSG_HIP(hipStreamWaitEvent(stream(), ev_up[s], 0));
+    PSG_HIP(hipMemcpyAsync(dlv[s].p, pin_lv[s], sizeof(MergeLevel) * (size_t)H, hipMemcpyHostToDevice, stream()));
+    PSG_HIP(hipEventRecord(ev_k0[s], stream()));
+    if ((rc = merge_launch(H, dlv[s].as<MergeLevel>(), pin_lv[s][0], pin_lv[s][H > 1 ? 1 : 0], any_hi, x0, cnt, dout[s].as<u8>()))) { result = rc; break; }
+    PSG_HIP(hipEventRecord(ev_k1[s], stream()));
+    if (check && (rc = psg::check_sa5_accumulate(check->d_text, check->n, dout[s].as<u8>(), cnt, check->samples_per_slice, check->seed + (u64)k, acc.as<unsigned long long>()))) { result = rc; break; }
+    if (sink) { PSG_HIP(hipMemcpyAsync(pin_out[s], dout[s].p, (size_t)(5 * cnt), hipMemcpyDeviceToHost, stream())); st.d2h_bytes += 5 * cnt; }
+    PSG_HIP(hipEventRecord(ev_dn[s], stream()));
+  }
+  (void)hipStreamSynchronize(up);
+  PSG_HIP(psg::sync_stream());
+  if (result) return result;
+  if (check) {
+    u64 h2[2];
+    if ((rc = psg::copy_d2h(h2, acc.p, 16))) return rc;
+    check->sum = h2[0]; check->bad_pairs = (i64)h2[1];
+  }
+  st.total_ms = wall_ms() - w0;
+  note_kernel_ms(st.kernel_ms);
+  if (stats) *stats = st;
   return 0;
 }

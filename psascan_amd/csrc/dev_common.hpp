@@ -48,7 +48,8 @@ void pool_free(void *p);
 void pool_trim();
 size_t pool_cached_bytes();   // bytes held in the cache (reusable without asking the driver)
 
-// grow-only pinned host buffers (slot 0..7), for small read-backs and the per-chain arrays
+// grow-only pinned host buffers (slot 0..15): 0-3 stream pass (per-chain arrays, read-backs), 4 wide-log slab
+// bounds, 7 copy staging, 8-11 streamed merge (PSA pieces in, .sa5 slices out), 12 merge cursors
 void *pinned_buf(int slot, size_t bytes);
 // Synchronous host<->device copies staged through pinned memory.  Pageable host pointers are never
 // handed to HIP: ROCr registers them as userptr ranges, and when the host later unmaps / trims
@@ -114,6 +115,10 @@ struct HistJob {
 };
 int gap_hist_launch(HistJob &job, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite);
 int gap_hist_wait(HistJob &job, double *ms);
+
+// property check of `count` packed uint40 entries (prep.hip): acc[0] += sum of the entries (mod 2^64),
+// acc[1] += number of `samples` random adjacent pairs that are NOT in suffix order.  Enqueued on stream().
+int check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i64 samples, u64 seed, unsigned long long *d_acc);
 
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);

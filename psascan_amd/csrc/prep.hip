@@ -202,17 +202,21 @@ __global__ __launch_bounds__(PSG_WG) void sa5_order_kernel(const u8 *text, i64 n
   i64 a = (i64)load_u40(sa5 + 5 * k), b = (i64)load_u40(sa5 + 5 * (k + 1));
   if (a >= n || b >= n || a == b || !suffix_less(text, n, a, b, 0)) atomicAdd(bad, 1ull);
 }
+int psg::check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i64 samples, u64 seed, unsigned long long *d_acc) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(sa5_sum_kernel, dim3((unsigned)std::min<i64>(cdiv(count, PSG_WG), 8192)), dim3(PSG_WG), 0, stream(), d_sa5, count, d_acc);
+  if (samples > 0) hipLaunchKernelGGL(sa5_order_kernel, dim3((unsigned)cdiv(samples, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, d_sa5, count, samples, seed, d_acc + 1);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples, uint64_t seed,
                               int64_t *bad_pairs, uint64_t *sum) {
   PSG_REQUIRE(d_text && d_sa5 && bad_pairs && sum && count >= 0, "psgx_check_sa5");
   DevBuf acc;
   if (int rc = acc.alloc(16)) return rc;
   PSG_HIP(hipMemsetAsync(acc.p, 0, 16, stream()));
-  if (count > 0) {
-    hipLaunchKernelGGL(sa5_sum_kernel, dim3((unsigned)std::min<i64>(cdiv(count, PSG_WG), 8192)), dim3(PSG_WG), 0, stream(), d_sa5, count, acc.as<unsigned long long>());
-    if (samples > 0) hipLaunchKernelGGL(sa5_order_kernel, dim3((unsigned)cdiv(samples, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, d_sa5, count, samples, seed, acc.as<unsigned long long>() + 1);
-    PSG_HIP(hipGetLastError());
-  }
+  if (int rc = psg::check_sa5_accumulate(d_text, n, d_sa5, count, samples, seed, acc.as<unsigned long long>())) return rc;
   u64 h[2];
   if (int rc_ = psg::copy_d2h(h, acc.p, (size_t)(16))) return rc_;
   PSG_HIP(psg::sync_stream());

@@ -48,6 +48,8 @@ static std::unordered_map<void *, std::pair<int, size_t>> g_big_live;   // block
 static const size_t BIG = (size_t)1 << 20, GRAN = (size_t)2 << 20, SEG_MAX = (size_t)8 << 30;
 
 static size_t pool_round(size_t b) { return (b + 4095) / 4096 * 4096; }
+static size_t g_in_use = 0, g_peak = 0, g_small_reserved = 0;   // guarded by g_pool_mu
+static void note_use(size_t add) { g_in_use += add; if (g_in_use > g_peak) g_peak = g_in_use; }
 
 static void *arena_carve(size_t need) {   // best fit over all segments; g_pool_mu held
   int bs = -1;
@@ -60,6 +62,7 @@ static void *arena_carve(size_t need) {   // best fit over all segments; g_pool_
   S.free.erase(boff);
   if (blen > need) S.free[boff + need] = blen - need;
   S.used += need;
+  note_use(need);
   void *p = S.base + boff;
   g_big_live[p] = {bs, need};
   return p;
@@ -115,6 +118,7 @@ hipError_t pool_alloc(void **p, size_t bytes) {
     if (it != g_pool_free.end() && it->first == need) {
       *p = it->second;
       g_pool_live[*p] = it->first;
+      note_use(it->first);
       g_pool_free.erase(it);
       return hipSuccess;
     }
@@ -125,7 +129,7 @@ hipError_t pool_alloc(void **p, size_t bytes) {
     pool_trim();
     e = hipMalloc(p, need);
   }
-  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_live[*p] = need; }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_live[*p] = need; note_use(need); g_small_reserved += need; }
   return e;
 }
 
@@ -138,6 +142,7 @@ void pool_free(void *p) {
     size_t off = (size_t)((char *)p - S.base), len = bg->second.second;
     g_big_live.erase(bg);
     S.used -= len;
+    g_in_use -= len;
     auto nx = S.free.lower_bound(off);
     if (nx != S.free.end() && off + len == nx->first) { len += nx->second; nx = S.free.erase(nx); }   // merge with the next range
     if (nx != S.free.begin()) {
@@ -150,6 +155,7 @@ void pool_free(void *p) {
   auto it = g_pool_live.find(p);
   if (it == g_pool_live.end()) { (void)hipFree(p); return; }
   g_pool_free.emplace(it->second, p);
+  g_in_use -= it->second;
   g_pool_live.erase(it);
 }
 
@@ -165,7 +171,7 @@ void pool_trim() {
   std::vector<void *> blocks;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto &kv : g_pool_free) blocks.push_back(kv.second);
+    for (auto &kv : g_pool_free) { blocks.push_back(kv.second); g_small_reserved -= kv.first; }
     g_pool_free.clear();
   }
   if (!blocks.empty() && g_stream) { (void)hipStreamSynchronize(g_stream); if (g_side) (void)hipStreamSynchronize(g_side); }
@@ -208,10 +214,10 @@ hipError_t sync_stream() {
 }
 
 // ---- pinned host scratch -----------------------------------------------------------------
-static void *g_pin[8] = {nullptr};
-static size_t g_pin_bytes[8] = {0};
+static void *g_pin[16] = {nullptr};
+static size_t g_pin_bytes[16] = {0};
 void *pinned_buf(int slot, size_t bytes) {
-  if (slot < 0 || slot >= 8) return nullptr;
+  if (slot < 0 || slot >= 16) return nullptr;
   if (bytes < 4096) bytes = 4096;
   if (g_pin_bytes[slot] >= bytes) return g_pin[slot];
   if (g_pin[slot]) { if (g_stream) (void)hipStreamSynchronize(g_stream);  /* rare: keep the blocking wait */ (void)hipHostFree(g_pin[slot]); g_pin[slot] = nullptr; g_pin_bytes[slot] = 0; }
@@ -221,29 +227,82 @@ void *pinned_buf(int slot, size_t bytes) {
   return g_pin[slot];
 }
 
-// ---- staged host <-> device copies ----------------------------------------------------------
-static const size_t STAGE_BYTES = (size_t)32 << 20;
-int copy_h2d(void *d, const void *h, size_t bytes) {
-  for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
-    size_t n = std::min(STAGE_BYTES, bytes - off);
-    void *pin = pinned_buf(7, n);
-    if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
-    memcpy(pin, (const char *)h + off, n);
-    PSG_HIP(hipMemcpyAsync((char *)d + off, pin, n, hipMemcpyHostToDevice, stream()));
-    PSG_HIP(sync_stream());
+// ---- host <-> device copies ------------------------------------------------------------------
+// Pinned host memory (psg_host_alloc, torch pinned tensors) is copied by one DMA.  Pageable memory goes through
+// TWO pinned staging buffers: the host fills one while the DMA drains the other, and the only waits are for the
+// buffer about to be refilled (was: one buffer, a full stream sync per 32 MiB piece).
+static const size_t STAGE_BYTES = (size_t)16 << 20;
+static bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+static hipError_t wait_event_poll(hipEvent_t e) {
+  hipError_t rc;
+  while ((rc = hipEventQuery(e)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
   }
-  return 0;
+  return rc;
+}
+int copy_h2d(void *d, const void *h, size_t bytes) {
+  if (bytes >= ((size_t)1 << 16) && is_pinned_host(h)) {
+    PSG_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream()));
+    PSG_HIP(sync_stream());
+    return 0;
+  }
+  char *pin = (char *)pinned_buf(7, 2 * std::min(STAGE_BYTES, std::max<size_t>(bytes, 4096)));
+  if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
+  const size_t piece = std::min(STAGE_BYTES, std::max<size_t>(bytes, 4096));
+  hipEvent_t ev[2] = {event_acquire(), event_acquire()};
+  bool used[2] = {false, false};
+  int rc = 0;
+  size_t k = 0;
+  for (size_t off = 0; off < bytes; off += piece, ++k) {
+    const int s = (int)(k & 1);
+    const size_t n = std::min(piece, bytes - off);
+    if (used[s] && wait_event_poll(ev[s]) != hipSuccess) { set_error("copy_h2d: device error"); rc = PSG_EDEVICE; break; }
+    memcpy(pin + s * piece, (const char *)h + off, n);
+    if (hipMemcpyAsync((char *)d + off, pin + s * piece, n, hipMemcpyHostToDevice, stream()) != hipSuccess ||
+        hipEventRecord(ev[s], stream()) != hipSuccess) { set_error("copy_h2d: hipMemcpyAsync failed"); rc = PSG_EDEVICE; break; }
+    used[s] = true;
+  }
+  hipError_t e = sync_stream();
+  event_release(ev[0]); event_release(ev[1]);
+  if (!rc && e != hipSuccess) { set_error(std::string("copy_h2d: ") + hipGetErrorString(e)); rc = PSG_EDEVICE; }
+  return rc;
 }
 int copy_d2h(void *h, const void *d, size_t bytes) {
-  for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
-    size_t n = std::min(STAGE_BYTES, bytes - off);
-    void *pin = pinned_buf(7, n);
-    if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
-    PSG_HIP(hipMemcpyAsync(pin, (const char *)d + off, n, hipMemcpyDeviceToHost, stream()));
+  if (bytes >= ((size_t)1 << 16) && is_pinned_host(h)) {
+    PSG_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream()));
     PSG_HIP(sync_stream());
-    memcpy((char *)h + off, pin, n);
+    return 0;
   }
-  return 0;
+  const size_t piece = std::min(STAGE_BYTES, std::max<size_t>(bytes, 4096));
+  char *pin = (char *)pinned_buf(7, 2 * piece);
+  if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
+  hipEvent_t ev[2] = {event_acquire(), event_acquire()};
+  int rc = 0;
+  const size_t np = (bytes + piece - 1) / piece;
+  for (size_t k = 0; k <= np; ++k) {     // piece k is in flight while piece k-1 is copied out of its staging buffer
+    if (k < np) {
+      const int s = (int)(k & 1);
+      const size_t off = k * piece, n = std::min(piece, bytes - off);
+      if (hipMemcpyAsync(pin + s * piece, (const char *)d + off, n, hipMemcpyDeviceToHost, stream()) != hipSuccess ||
+          hipEventRecord(ev[s], stream()) != hipSuccess) { set_error("copy_d2h: hipMemcpyAsync failed"); rc = PSG_EDEVICE; break; }
+    }
+    if (k >= 1) {
+      const int s = (int)((k - 1) & 1);
+      const size_t off = (k - 1) * piece, n = std::min(piece, bytes - off);
+      if (wait_event_poll(ev[s]) != hipSuccess) { set_error("copy_d2h: device error"); rc = PSG_EDEVICE; break; }
+      memcpy((char *)h + off, pin + s * piece, n);
+    }
+  }
+  hipError_t e = sync_stream();
+  event_release(ev[0]); event_release(ev[1]);
+  if (!rc && e != hipSuccess) { set_error(std::string("copy_d2h: ") + hipGetErrorString(e)); rc = PSG_EDEVICE; }
+  return rc;
 }
 
 // ---- single-workgroup scan ------------------------------------------------------------
@@ -387,6 +446,29 @@ int psg_d2d(void *dd, const void *ds, int64_t bytes) {
   return 0;
 }
 int psg_sync(void) { PSG_HIP(psg::sync_stream()); return 0; }
+int psg_host_alloc(void **h_ptr, int64_t bytes) {
+  PSG_REQUIRE(h_ptr && bytes >= 0, "psg_host_alloc");
+  *h_ptr = nullptr;
+  hipError_t e = hipHostMalloc(h_ptr, (size_t)(bytes < 16 ? 16 : bytes), hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e)); *h_ptr = nullptr; return PSG_ENOMEM; }
+  return 0;
+}
+int psg_host_free(void *h_ptr) {
+  if (!h_ptr) return 0;
+  (void)psg::sync_stream();
+  if (g_side) (void)hipStreamSynchronize(g_side);
+  PSG_HIP(hipHostFree(h_ptr));
+  return 0;
+}
+int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  size_t res = g_small_reserved;
+  for (auto &S : g_segs) res += S.size;
+  if (in_use) *in_use = (int64_t)g_in_use;
+  if (peak_in_use) *peak_in_use = (int64_t)g_peak;
+  if (reserved) *reserved = (int64_t)res;
+  return 0;
+}
 
 int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t src_bit, int64_t nbits) {
   PSG_REQUIRE(dst_bit >= 0 && src_bit >= 0 && nbits >= 0, "psg_bitcopy");

@@ -592,6 +592,65 @@ def test_merge_vs_oracle(A, cuts):
     assert np.array_equal(A.download(d_part, np.uint8, 5 * 1234), want[5 * 777: 5 * (777 + 1234)])
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("cuts", [[0, 30000], [0, 14000, 30000], [0, 700, 1500, 1501, 9600, 13333, 24100, 30000],
+                                  list(range(0, 30001, 1500))])
+def test_merge_stream_vs_oracle(A, cuts, pinned):
+    """merge<T> with the partial SAs in host memory (the reference streams them from part files, merge.hpp:72-81):
+    slices of 2048 outputs -> 15 slices, every half-block's PSA is consumed in pieces; bytes equal the oracle's."""
+    rng = np.random.default_rng(14)
+    n = cuts[-1]
+    t = rng.integers(0, 3, n, dtype=np.uint8)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    hbs, begs, sizes, psas, gaps, keep = [], [], [], [], [], []
+    for h in range(len(cuts) - 1):
+        b, e = cuts[h], cuts[h + 1]
+        psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+        ranks = np.searchsorted(np.sort(isa[b:e]), isa[e:n])
+        g = np.bincount(ranks, minlength=e - b + 1).astype(np.uint64)
+        begs.append(b); sizes.append(e - b); psas.append(psa); gaps.append(g if e < n else None)
+        mbv = None
+        if e < n:
+            bv, nb = orc.gap_to_bitvector(g, e - b)
+            mbv = A.upload(bv[: (nb + 7) // 8])
+        lo = psa.astype(np.uint32)
+        if pinned:
+            pa = A.PinnedArray(len(lo), np.uint32)
+            pa.array[:] = lo
+            keep.append(pa)
+            lo = pa.array
+        hbs.append({"beg": b, "size": e - b, "psa_lo": lo, "psa_hi": None, "mbv": mbv})
+    want = orc.merge(begs, sizes, psas, gaps)
+    got = np.zeros(5 * n, np.uint8)
+    calls = []
+
+    def sink(view, first, cnt):
+        got[5 * first: 5 * (first + cnt)] = view
+        calls.append((first, cnt))
+
+    d_text = A.upload(t, pad_to=16)
+    st, chk = A.merge_stream(hbs, 2048, sink, check_text=d_text, n=n, samples_per_slice=512, seed=3)
+    assert np.array_equal(got, want)
+    assert calls == [(k * 2048, min(2048, n - k * 2048)) for k in range((n + 2047) // 2048)]
+    assert chk == ((n * (n - 1) // 2) % (1 << 64), 0)
+    assert st.slices == len(calls) and st.h2d_bytes == 4 * n and st.d2h_bytes == 5 * n
+    # output dropped on the device (bench mode): only the check comes back
+    st2, chk2 = A.merge_stream(hbs, 4096, None, check_text=d_text, n=n, samples_per_slice=512, seed=4)
+    assert chk2 == chk and st2.d2h_bytes == 0
+
+
+def test_merge_stream_high_byte(A):
+    psa0 = np.array([3, 2 ** 32 + 5, 7], np.uint64)
+    psa1 = np.array([1, 0], np.uint64)
+    bv = orc.packbits([0, 1, 0, 1, 0])
+    hbs = [{"beg": 10, "size": 3, "psa_lo": (psa0 & np.uint64(0xFFFFFFFF)).astype(np.uint32), "psa_hi": (psa0 >> np.uint64(32)).astype(np.uint8), "mbv": A.upload(bv)},
+           {"beg": 2 ** 39, "size": 2, "psa_lo": psa1.astype(np.uint32), "psa_hi": None, "mbv": None}]
+    out = []
+    A.merge_stream(hbs, 2048, lambda v, f, c: out.append(v.copy()))
+    assert list(orc.sa5_to_sa(np.concatenate(out))) == [13, 2 ** 39 + 1, 2 ** 32 + 15, 2 ** 39, 17]
+
+
 def test_merge_high_byte(A):
     """half-block offsets beyond 2^32 (psa_hi) and beg beyond 2^32: uint40 packing."""
     psa0 = np.array([3, 2 ** 32 + 5, 7], np.uint64)
