@@ -11,11 +11,14 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* seeded text: mode 0 = uniform bytes 0..254, 1 = DNA (ACGT), 2 = `sigma` letters from 'a' */
+/* seeded text: mode 0 = uniform bytes 0..254, 1 = DNA (ACGT), 2 = `sigma` letters from 'a',
+ * 3 = English-like (Zipfian words over a skewed 26-letter alphabet, blanks, full stops: sigma = 28) */
 int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, uint64_t seed);
 /* partial SA (relative to beg), BWT (dummy 0 at i0), i0 and gt_begin (bit u <-> position
  * end-u, u in [0,size)) of text[beg..end) ordered as suffixes of the whole text.  Prefix-key
- * radix sort + comparison of equal-key groups: only for texts with short repeats.        */
+ * radix sort + refinement rounds on the following symbols (groups of equal prefixes are re-sorted by
+ * the next 8-12 symbols, up to 24 rounds) + comparison of what is left: for texts whose repeats are
+ * at most a few hundred symbols long (random, DNA, the English-like generator).              */
 int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa,
                         uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups);
 /* property check of `count` uint40 entries: sum of entries mod 2^64, and the number of sampled

@@ -7,8 +7,12 @@
 // (rocPRIM radix sort) and finish the rare equal-key groups by direct suffix comparison.
 #include "dev_common.hpp"
 
+#include <cmath>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -38,9 +42,79 @@ __global__ __launch_bounds__(PSG_WG) void gen_text_kernel(u8 *text, i64 n, int m
   }
 }
 
+// mode 3: "English-like" text (BASELINE configs[2]; no corpus ships with the image): words drawn from a Zipfian
+// table of 4096 words over a skewed 26-letter alphabet, separated by blanks, a full stop now and then -- sigma = 28,
+// frequent symbols next to rare ones, repeats of tens of symbols.  Every thread fills one 256-byte segment from its
+// own seed (words are cut at segment ends), so the text is a pure function of (seed, n).
+#define ENG_WORDS 4096
+#define ENG_SEG 256
+struct EngTable { u32 cum[ENG_WORDS]; u16 off[ENG_WORDS + 1]; u8 letters[ENG_WORDS * 10]; };
+__global__ __launch_bounds__(PSG_WG) void gen_english_kernel(u8 *text, i64 n, const EngTable *tab, u64 seed) {
+  __shared__ __attribute__((aligned(16))) u8 buf[PSG_WG][ENG_SEG + 16];   // +16: rows on different banks
+  const i64 seg = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  u8 *b = buf[threadIdx.x];
+  u64 r = splitmix64(seed * 0x100000001B3ull + (u64)seg);
+  int len = 0;
+  while (len < ENG_SEG) {
+    r = splitmix64(r);
+    const u32 x = (u32)(r >> 32);
+    int lo = 0, hi = ENG_WORDS - 1;                      // first word with cum >= x
+    while (lo < hi) { int md = (lo + hi) >> 1; if (tab->cum[md] >= x) hi = md; else lo = md + 1; }
+    const int o = tab->off[lo], l = tab->off[lo + 1] - o;
+    for (int q = 0; q < l && len < ENG_SEG; ++q) b[len++] = tab->letters[o + q];
+    if (len < ENG_SEG) b[len++] = ((u32)r & 15u) == 0 ? '.' : ' ';
+    if (len < ENG_SEG && b[len - 1] == '.') b[len++] = ' ';
+  }
+  __syncthreads();
+  // coalesced copy-out: 16 lanes x 16 bytes per segment
+  const i64 base = (i64)blockIdx.x * PSG_WG * ENG_SEG;
+  for (int k = threadIdx.x; k < PSG_WG * (ENG_SEG / 16); k += PSG_WG) {
+    const int sg = k / (ENG_SEG / 16), q = k % (ENG_SEG / 16);
+    const i64 p = base + (i64)sg * ENG_SEG + q * 16;
+    if (p + 16 <= n) *(uint4 *)(text + p) = *(const uint4 *)(buf[sg] + q * 16);
+    else for (int j = 0; j < 16 && p + j < n; ++j) text[p + j] = buf[sg][q * 16 + j];
+  }
+}
+
+static void build_english_table(EngTable &T) {
+  u64 r = 0x5EED5EEDull;
+  auto next = [&] { r += 0x9E3779B97F4A7C15ull; u64 x = r; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
+  const char *letters = "etaoinshrdlcumwfgypbvkjxqz";
+  double lp[26], lsum = 0;
+  for (int k = 0; k < 26; ++k) { lp[k] = 1.0 / std::pow(k + 1.0, 0.9); lsum += lp[k]; }
+  int o = 0;
+  for (int w = 0; w < ENG_WORDS; ++w) {
+    T.off[w] = (u16)o;
+    const int l = 2 + (int)(next() % 8);
+    for (int q = 0; q < l; ++q) {
+      double x = (double)(next() >> 11) / 9007199254740992.0 * lsum;
+      int k = 0;
+      while (k < 25 && x >= lp[k]) { x -= lp[k]; ++k; }
+      T.letters[o++] = (u8)letters[k];
+    }
+  }
+  T.off[ENG_WORDS] = (u16)o;
+  double wsum = 0, run = 0;
+  for (int w = 0; w < ENG_WORDS; ++w) wsum += 1.0 / (w + 1.0);
+  for (int w = 0; w < ENG_WORDS; ++w) { run += 1.0 / (w + 1.0) / wsum; T.cum[w] = w == ENG_WORDS - 1 ? 0xFFFFFFFFu : (u32)std::min(4294967295.0, run * 4294967296.0); }
+}
+
 extern "C" int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, uint64_t seed) {
-  PSG_REQUIRE(d_text && n >= 0 && mode >= 0 && mode <= 2, "psgx_gen_text");
+  PSG_REQUIRE(d_text && n >= 0 && mode >= 0 && mode <= 3, "psgx_gen_text");
   if (n == 0) return 0;
+  if (mode == 3) {
+    PSG_REQUIRE(((uintptr_t)d_text & 15) == 0, "psgx_gen_text: text must be 16-byte aligned");
+    static EngTable T;
+    static bool built = false;
+    if (!built) { build_english_table(T); built = true; }
+    DevBuf tab;
+    if (int rc = tab.alloc(sizeof(EngTable))) return rc;
+    if (int rc = psg::copy_h2d(tab.p, &T, sizeof(EngTable))) return rc;
+    hipLaunchKernelGGL(gen_english_kernel, dim3((unsigned)cdiv(cdiv(n, ENG_SEG), PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, tab.as<EngTable>(), seed);
+    PSG_HIP(hipGetLastError());
+    PSG_HIP(psg::sync_stream());
+    return 0;
+  }
   hipLaunchKernelGGL(gen_text_kernel, dim3((unsigned)cdiv(cdiv(n, 8), PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, mode, sigma, seed);
   PSG_HIP(hipGetLastError());
   PSG_HIP(psg::sync_stream());
@@ -92,15 +166,54 @@ __device__ bool suffix_less(const u8 *text, i64 n, i64 a, i64 b, i64 skip) {
   return a + k >= n && b + k < n ? true : (a + k >= n && b + k >= n ? a > b : false);
 }
 
-// one thread per equal-key group (the group head does the work): insertion sort by suffix comparison
-__global__ __launch_bounds__(PSG_WG) void fix_ties_kernel(const u8 *text, i64 n, i64 beg, i64 size, const u64 *keys, u32 *idx, int skip,
+// ---- refinement rounds: groups of suffixes that agree on their first d symbols are re-sorted by the next
+// per_key symbols (keys read straight from the text, so nothing depends on ranks of other positions).
+// head[k] = 1: sorted position k starts a group.
+__global__ __launch_bounds__(PSG_WG) void heads_from_keys_kernel(const u64 *keys, i64 size, u8 *head) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k < size) head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0;
+}
+// unresolved = member of a group with more than one element
+__global__ __launch_bounds__(PSG_WG) void unresolved_kernel(const u8 *head, i64 size, u8 *flag) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k < size) flag[k] = (head[k] && (k + 1 == size || head[k + 1])) ? 0 : 1;
+}
+// compacted element j (sorted position upos[j]): group start marker (its own index where a group starts, else 0)
+__global__ __launch_bounds__(PSG_WG) void group_start_kernel(const u32 *upos, const u8 *head, i64 nu, u32 *start) {
+  i64 j = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (j < nu) start[j] = head[upos[j]] ? (u32)j : 0u;
+}
+__global__ __launch_bounds__(PSG_WG) void round_keys_kernel(const u8 *text, i64 n, i64 beg, KeyCfg cfg, i64 depth, const u32 *upos, const u32 *idx,
+                                                             const u32 *gid, i64 nu, u64 *key2, u64 *packed) {
+  i64 j = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (j >= nu) return;
+  const u32 s = idx[upos[j]];
+  u64 key = 0;
+  const i64 p = beg + (i64)s + depth;
+  for (int q = 0; q < cfg.per_key; ++q) {
+    u64 v = p + q < n ? (u64)cfg.code[text[p + q]] + 1 : 0;
+    key = (key << cfg.bits) | v;
+  }
+  key2[j] = key;
+  packed[j] = ((u64)gid[j] << 32) | s;
+}
+__global__ __launch_bounds__(PSG_WG) void round_scatter_kernel(const u32 *upos, const u64 *packed, const u64 *key2, i64 nu, u32 *idx, u8 *head) {
+  i64 j = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (j >= nu) return;
+  const u32 k = upos[j];
+  idx[k] = (u32)packed[j];
+  head[k] = (j == 0 || (packed[j] >> 32) != (packed[j - 1] >> 32) || key2[j] != key2[j - 1]) ? 1 : 0;
+}
+
+// what is left after the rounds: one thread per group (the group head does the work), insertion sort by suffix comparison
+__global__ __launch_bounds__(PSG_WG) void fix_ties_kernel(const u8 *text, i64 n, i64 beg, i64 size, const u8 *head, u32 *idx, i64 skip,
                                                             int max_group, unsigned long long *groups, int *too_big) {
   i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (k >= size) return;
-  if (k > 0 && keys[k - 1] == keys[k]) return;           // not a group head
-  if (k + 1 >= size || keys[k + 1] != keys[k]) return;   // singleton
+  if (!head[k]) return;                                   // not a group head
+  if (k + 1 >= size || head[k + 1]) return;               // singleton
   i64 e = k + 1;
-  while (e < size && keys[e] == keys[k]) ++e;
+  while (e < size && !head[e]) ++e;
   if (e - k > max_group) { *too_big = 1; return; }
   atomicAdd(groups, 1ull);
   for (i64 a = k + 1; a < e; ++a) {
@@ -165,8 +278,57 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
   if ((rc = tmp.alloc((i64)tbytes))) return rc;
   PSG_HIP(rocprim::radix_sort_pairs(tmp.p, tbytes, keys_a.as<u64>(), keys_b.as<u64>(), idx_b.as<u32>(), d_psa, (size_t)size, 0, 64, stream()));
   PSG_HIP(hipMemsetAsync(misc.p, 0, 32, stream()));
-  hipLaunchKernelGGL(fix_ties_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, keys_b.as<u64>(), d_psa,
-                     cfg.per_key, 4096, misc.as<unsigned long long>(), (int *)((u8 *)misc.p + 8));
+  // ---- refinement rounds (English-like text leaves most suffixes tied after the first 8-12 symbols)
+  DevBuf head;
+  if ((rc = head.alloc(size + 16))) return rc;
+  hipLaunchKernelGGL(heads_from_keys_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), keys_b.as<u64>(), size, head.as<u8>());
+  PSG_HIP(hipGetLastError());
+  keys_a.alloc(16); keys_b.alloc(16); idx_b.alloc(16); tmp.alloc(16);
+  i64 depth = cfg.per_key;
+  const int max_rounds = 24;
+  for (int round = 0; round < max_rounds; ++round, depth += cfg.per_key) {
+    DevBuf flag, upos, cnt;
+    if ((rc = flag.alloc(size)) || (rc = upos.alloc(size * 4)) || (rc = cnt.alloc(8))) return rc;
+    hipLaunchKernelGGL(unresolved_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), head.as<u8>(), size, flag.as<u8>());
+    PSG_HIP(hipGetLastError());
+    size_t tb2 = 0;
+    rocprim::counting_iterator<u32> positions(0);
+    PSG_HIP(rocprim::select(nullptr, tb2, positions, flag.as<u8>(), upos.as<u32>(), cnt.as<u64>(), (size_t)size, stream()));
+    DevBuf t2;
+    if ((rc = t2.alloc((i64)tb2))) return rc;
+    PSG_HIP(rocprim::select(t2.p, tb2, positions, flag.as<u8>(), upos.as<u32>(), cnt.as<u64>(), (size_t)size, stream()));
+    u64 nu64 = 0;
+    if (int rc_ = psg::copy_d2h(&nu64, cnt.p, 8)) return rc_;
+    const i64 nu = (i64)nu64;
+    flag.alloc(16);
+    if (nu == 0) break;
+    DevBuf start, gid, key2a, key2b, pka, pkb;
+    if ((rc = start.alloc(nu * 4)) || (rc = gid.alloc(nu * 4)) || (rc = key2a.alloc(nu * 8)) || (rc = key2b.alloc(nu * 8)) || (rc = pka.alloc(nu * 8)) || (rc = pkb.alloc(nu * 8))) return rc;
+    const unsigned gnu = (unsigned)cdiv(nu, PSG_WG);
+    hipLaunchKernelGGL(group_start_kernel, dim3(gnu), dim3(PSG_WG), 0, stream(), upos.as<u32>(), head.as<u8>(), nu, start.as<u32>());
+    size_t tb3 = 0;
+    PSG_HIP(rocprim::inclusive_scan(nullptr, tb3, start.as<u32>(), gid.as<u32>(), (size_t)nu, rocprim::maximum<u32>(), stream()));
+    if ((rc = t2.alloc((i64)tb3))) return rc;
+    PSG_HIP(rocprim::inclusive_scan(t2.p, tb3, start.as<u32>(), gid.as<u32>(), (size_t)nu, rocprim::maximum<u32>(), stream()));
+    hipLaunchKernelGGL(round_keys_kernel, dim3(gnu), dim3(PSG_WG), 0, stream(), d_text, n, beg, cfg, depth, upos.as<u32>(), d_psa, gid.as<u32>(), nu, key2a.as<u64>(), pka.as<u64>());
+    PSG_HIP(hipGetLastError());
+    start.alloc(16); gid.alloc(16);
+    // stable sort by the new key, then by the group: (group, key) order
+    const unsigned kbits = (unsigned)(cfg.per_key * cfg.bits);
+    unsigned gbits = 1;
+    while (((u64)1 << gbits) < (u64)nu) ++gbits;
+    size_t tb4 = 0, tb5 = 0;
+    PSG_HIP(rocprim::radix_sort_pairs(nullptr, tb4, key2a.as<u64>(), key2b.as<u64>(), pka.as<u64>(), pkb.as<u64>(), (size_t)nu, 0, kbits, stream()));
+    PSG_HIP(rocprim::radix_sort_pairs(nullptr, tb5, pkb.as<u64>(), pka.as<u64>(), key2b.as<u64>(), key2a.as<u64>(), (size_t)nu, 32, 32 + gbits, stream()));
+    if ((rc = t2.alloc((i64)std::max(tb4, tb5)))) return rc;
+    PSG_HIP(rocprim::radix_sort_pairs(t2.p, tb4, key2a.as<u64>(), key2b.as<u64>(), pka.as<u64>(), pkb.as<u64>(), (size_t)nu, 0, kbits, stream()));
+    PSG_HIP(rocprim::radix_sort_pairs(t2.p, tb5, pkb.as<u64>(), pka.as<u64>(), key2b.as<u64>(), key2a.as<u64>(), (size_t)nu, 32, 32 + gbits, stream()));
+    hipLaunchKernelGGL(round_scatter_kernel, dim3(gnu), dim3(PSG_WG), 0, stream(), upos.as<u32>(), pka.as<u64>(), key2a.as<u64>(), nu, d_psa, head.as<u8>());
+    PSG_HIP(hipGetLastError());
+    PSG_HIP(psg::sync_stream());   // the round's buffers go back to the arena
+  }
+  hipLaunchKernelGGL(fix_ties_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, head.as<u8>(), d_psa,
+                     depth, 4096, misc.as<unsigned long long>(), (int *)((u8 *)misc.p + 8));
   PSG_HIP(hipGetLastError());
   hipLaunchKernelGGL(find_i0_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_psa, size, (i64 *)((u8 *)misc.p + 16));
   if (d_gt_begin) PSG_HIP(hipMemsetAsync(d_gt_begin, 0, (size_t)(((size + 31) >> 5) * 4), stream()));

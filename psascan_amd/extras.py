@@ -6,7 +6,7 @@ import ctypes as C
 from ._lib import check, lib
 from .api import DeviceBuffer, _ptr, zeros
 
-MODE_BYTES255, MODE_DNA, MODE_LETTERS = 0, 1, 2
+MODE_BYTES255, MODE_DNA, MODE_LETTERS, MODE_ENGLISH = 0, 1, 2, 3
 
 
 def gen_text(n, mode=MODE_BYTES255, sigma=0, seed=1, d_text=None):

@@ -8,7 +8,27 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode,sigma,mib,block_mib", [(0, 0, 192, 48), (1, 0, 160, 64), (2, 12, 96, 20)])
+def test_device_sorter_english_like_vs_oracle(gpu_lib):
+    """the bench's input preparation on configs[2]-like text: device generator (mode 3) + prefix-key sorter with
+    refinement rounds, against the oracle's partial SA / BWT / gt bits of the same half-block"""
+    import orc
+    from psascan_amd import api, extras
+    n = 300_000
+    d_text = extras.gen_text(n, extras.MODE_ENGLISH, 0, seed=5)
+    t = api.download(d_text, np.uint8, n)
+    assert set(np.unique(t)) <= set(b"etaoinshrdlcumwfgypbvkjxqz .") and len(np.unique(t)) >= 20
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    for b, e in [(0, n), (n // 3, 2 * n // 3), (n // 2, n)]:
+        r = extras.sort_halfblock(d_text, n, b, e)
+        psa, bwt, i0, gt = orc.partial_sa(t, sa, isa, b, e)
+        m = e - b
+        assert np.array_equal(api.download(r["psa_lo"], np.uint32, m).astype(np.int64), psa), (b, e)
+        assert np.array_equal(api.download(r["bwt"], np.uint8, m), bwt) and r["i0"] == i0
+        assert np.array_equal(orc.bits(api.download(r["gt_begin"], np.uint8, (m + 7) // 8), m), orc.bits(gt, m))
+
+
+@pytest.mark.parametrize("mode,sigma,mib,block_mib", [(0, 0, 192, 48), (1, 0, 160, 64), (2, 12, 96, 20), (3, 0, 128, 40)])
 def test_multiblock_properties(gpu_lib, mode, sigma, mib, block_mib):
     from psascan_amd import api, extras, pipeline
     n = (mib << 20) + 12345
