@@ -89,7 +89,7 @@ typedef struct {
   int64_t n_chains;        /* chains actually used                                  */
   int64_t chain_len;       /* steps per chain                                       */
   int64_t warmup_steps;    /* warm-up steps per chain boundary (last attempt)       */
-  int64_t unresolved;      /* chain starts that needed the sequential fallback      */
+  int64_t unresolved;      /* chain starts the warm-up left open (found by search, or run one after another) */
   int64_t rounds;          /* stream kernel launches                                */
   double kernel_ms;        /* time of the stream kernel launches (HIP events)       */
   double total_ms;         /* whole call                                            */
@@ -125,6 +125,49 @@ int psg_stream_gap_ex(const psg_rank_t *rank, int64_t block_i0, int block_last_s
                       const uint32_t *d_gt_in, int64_t rank_at_context_end, uint32_t *d_gap,
                       uint32_t *d_gt_out, int64_t max_chains, int flags, int64_t *h_final_rank,
                       psg_stream_stats *stats);
+
+/* ---- em_compute_initial_ranks, partial_sufsort.hpp:189,311,385 (em_compute_initial_ranks.hpp:222-319,
+ *      513-561; lcp_compare :54-76): exact rank of a tail suffix among the suffixes of a block, by string search
+ *      over the block's partial suffix array(s).  A comparison that reaches `cmp_end` (the end of the block being
+ *      processed) is decided by the gt bit of the position the pattern has reached.  The whole text is one device
+ *      array.  A streaming pass given a search context resolves every chain start whose warm-up interval does not
+ *      close (text with long repeats) this way, in one launch, instead of running those chains one after another. */
+typedef struct {
+  const uint8_t *d_text;          /* text[0..n) on the device                                               */
+  int64_t n;
+  int64_t cmp_end;                /* comparisons run on text symbols while the block suffix is below cmp_end */
+  const uint32_t *d_gt_cmp_end;   /* bit (n - j) = [text[j..n) > text[cmp_end..n)], j in (cmp_end, n]; may be
+                                     NULL when cmp_end == n                                                  */
+  int nparts;                     /* 1 or 2 sorted parts (half-blocks), all below cmp_end                    */
+  struct { int64_t beg, size; const uint32_t *d_psa_lo; const uint8_t *d_psa_hi; } part[2];
+} psg_search_ctx;
+/* h_ranks[k] = sum over the parts of #{s in part : text[s..n) < text[h_positions[k]..n)}; positions lie at or
+ * behind the end of the last part (position n: rank 0).                                                       */
+int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_positions, int64_t count, int64_t *h_ranks);
+
+/* One streaming pass, all arguments in a struct (psg_stream_gap_ex + search context).  With `search` set, chain
+ * starts the warm-up cannot determine are found by psg_initial_ranks' search: `tail_begin_abs` = text position of
+ * d_tail[0].  flags: PSG_GAP_UNINITIALIZED, PSG_FAIL_IF_UNRESOLVED (return PSG_EUNRESOLVED instead of running
+ * unresolved chains one after another when no search context is given: the caller uploads the partial SAs and
+ * calls again).                                                                                               */
+#define PSG_FAIL_IF_UNRESOLVED 2
+#define PSG_EUNRESOLVED (-6)
+typedef struct {
+  const psg_rank_t *rank;
+  int64_t block_i0;
+  int block_last_symbol;
+  const uint8_t *d_tail;
+  int64_t tail_len, right_context;
+  const uint32_t *d_gt_in;
+  int64_t rank_at_context_end;
+  uint32_t *d_gap;
+  uint32_t *d_gt_out;
+  int64_t max_chains;
+  int flags;
+  const psg_search_ctx *search;   /* may be NULL */
+  int64_t tail_begin_abs;         /* used with `search` */
+} psg_stream_args;
+int psg_stream_gap_args(const psg_stream_args *a, int64_t *h_final_rank, psg_stream_stats *stats);
 
 /* ---- buffered_gap_array::convert_to_bitvector, partial_sufsort.hpp:441
  *      (gap_array.hpp:273-364): for j=0..m: gap[j] ones, then a zero (none after j=m).

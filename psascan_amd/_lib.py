@@ -35,6 +35,22 @@ class MergeStreamStatsC(C.Structure):
                 ("sink_ms", C.c_double), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64)]
 
 
+class SearchPartC(C.Structure):
+    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p)]
+
+
+class SearchCtxC(C.Structure):
+    _fields_ = [("d_text", C.c_void_p), ("n", C.c_int64), ("cmp_end", C.c_int64), ("d_gt_cmp_end", C.c_void_p), ("nparts", C.c_int),
+                ("part", SearchPartC * 2)]
+
+
+class StreamArgsC(C.Structure):
+    _fields_ = [("rank", C.c_void_p), ("block_i0", C.c_int64), ("block_last_symbol", C.c_int), ("d_tail", C.c_void_p),
+                ("tail_len", C.c_int64), ("right_context", C.c_int64), ("d_gt_in", C.c_void_p), ("rank_at_context_end", C.c_int64),
+                ("d_gap", C.c_void_p), ("d_gt_out", C.c_void_p), ("max_chains", C.c_int64), ("flags", C.c_int),
+                ("search", C.POINTER(SearchCtxC)), ("tail_begin_abs", C.c_int64)]
+
+
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
 
 # every symbol include/psascan_amd.h declares: name -> (restype, argtypes)
@@ -63,6 +79,8 @@ SIGNATURES = {
     "psg_stream_gap": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_stream_gap_ctx": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
     "psg_stream_gap_ex": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_stream_gap_args": (_int, [C.POINTER(StreamArgsC), C.POINTER(_i64), C.POINTER(StreamStatsC)]),
+    "psg_initial_ranks": (_int, [C.POINTER(SearchCtxC), C.POINTER(_i64), _i64, C.POINTER(_i64)]),
     "psg_stream_gap_log": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(StreamStatsC),
                                   C.POINTER(_vp), C.POINTER(_i64)]),
     "psg_log_partition": (_int, [_vp, _i64, _i64, _int, _vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import HbDescC, HbHostDescC, MergeCheckC, MergeStreamStatsC, SINK_FN, StreamStatsC, check, lib
+from ._lib import (HbDescC, HbHostDescC, MergeCheckC, MergeStreamStatsC, SINK_FN, SearchCtxC, StreamArgsC, StreamStatsC, check, lib)
 
 
 class DeviceBuffer:
@@ -118,14 +118,43 @@ class StreamStats:
         return "StreamStats(" + ", ".join(f"{k}={getattr(self, k)}" for k, _ in StreamStatsC._fields_) + ")"
 
 
+PSG_GAP_UNINITIALIZED, PSG_FAIL_IF_UNRESOLVED, PSG_EUNRESOLVED = 1, 2, -6
+
+
+def search_ctx(d_text, n, cmp_end, d_gt_cmp_end, parts):
+    """psg_search_ctx: parts = [(beg, size, d_psa_lo, d_psa_hi or None)] (1 or 2 half-blocks below cmp_end);
+    d_gt_cmp_end: bit (n - j) = [text[j..) > text[cmp_end..)]."""
+    sc = SearchCtxC()
+    sc.d_text, sc.n, sc.cmp_end, sc.d_gt_cmp_end, sc.nparts = _ptr(d_text), n, cmp_end, _ptr(d_gt_cmp_end), len(parts)
+    for k, (beg, size, lo, hi) in enumerate(parts):
+        sc.part[k].beg, sc.part[k].size, sc.part[k].d_psa_lo, sc.part[k].d_psa_hi = beg, size, _ptr(lo), _ptr(hi)
+    sc._keep = (d_text, d_gt_cmp_end, parts)
+    return sc
+
+
+def initial_ranks(sc, positions):
+    """em_compute_initial_ranks: #block suffixes smaller than text[p..n) for every p (string search on the device)."""
+    pos = np.ascontiguousarray(positions, np.int64)
+    out = np.zeros(len(pos), np.int64)
+    check(lib().psg_initial_ranks(C.byref(sc), pos.ctypes.data_as(C.POINTER(C.c_int64)), len(pos), out.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
+
+
 def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_tail_end, d_gap, d_gt_out,
-               max_chains=0, right_context=0, fresh_gap=False):
+               max_chains=0, right_context=0, fresh_gap=False, search=None, tail_begin_abs=0, fail_if_unresolved=False):
     """One streaming pass (compute_gap<T>), optionally over a sub-range of the tail with
     `right_context` bytes/bits of valid text/gt to its right.  fresh_gap: d_gap is uninitialised
     (the reference's freshly constructed gap array) -- the pass zero-fills / overwrites it.
+    search: psg_search_ctx for the chain starts the warm-up leaves open (tail_begin_abs = position of d_tail[0]).
     Returns (final_rank, StreamStats)."""
     fin = C.c_int64(0)
     st = StreamStatsC()
+    if search is not None or fail_if_unresolved:
+        a = StreamArgsC(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context, _ptr(d_gt_in), rank_at_tail_end,
+                        _ptr(d_gap), _ptr(d_gt_out), max_chains, (1 if fresh_gap else 0) | (2 if fail_if_unresolved else 0),
+                        C.pointer(search) if search is not None else None, tail_begin_abs)
+        check(lib().psg_stream_gap_args(C.byref(a), C.byref(fin), C.byref(st)))
+        return fin.value, StreamStats(st)
     if fresh_gap:
         check(lib().psg_stream_gap_ex(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context,
                                       _ptr(d_gt_in), rank_at_tail_end, _ptr(d_gap), _ptr(d_gt_out), max_chains, 1,

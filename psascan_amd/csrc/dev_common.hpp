@@ -120,6 +120,9 @@ int gap_hist_wait(HistJob &job, double *ms);
 // acc[1] += number of `samples` random adjacent pairs that are NOT in suffix order.  Enqueued on stream().
 int check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i64 samples, u64 seed, unsigned long long *d_acc);
 
+// K8 (search.hip): enqueue the string search for npos device-resident positions; ranks land in d_rank
+int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank);
+
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);
 

@@ -950,30 +950,57 @@ template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mod
 #undef PSG_OCC
 }
 
+// everything one pass needs (the public entry points differ only in how they fill this in)
+struct PassArgs {
+  const psg_rank_t *r;
+  i64 i0;
+  int last_sym;
+  const u8 *d_tail;
+  i64 T, ctx;
+  const u32 *d_gt_in;
+  i64 rank_at_end;
+  u32 *d_gap;
+  u32 *d_gt_out;
+  i64 max_chains;
+  bool fresh;                     // PSG_GAP_UNINITIALIZED
+  bool fail_if_unresolved;        // PSG_FAIL_IF_UNRESOLVED
+  const psg_search_ctx *search;   // K8 for chain starts the warm-up leaves open
+  i64 tail_begin_abs;
+  u32 **log_out;
+  i64 *nlog_out;
+};
+static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats);
+static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats);
+
 extern "C" int psg_stream_gap(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                               const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out,
                               int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
   return psg_stream_gap_ctx(r, i0, last_sym, d_tail, T, 0, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats);
 }
 
-static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
-                       const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh);
-
 extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                                   int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
                                   uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
   PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
-  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr, false);
+  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, false, false, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
 }
 // the gap array is uninitialised on entry (PSG_GAP_UNINITIALIZED): zero-filled or overwritten by the pass
 extern "C" int psg_stream_gap_ex(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
                                  int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
                                  uint32_t *d_gt_out, int64_t max_chains, int flags, int64_t *h_final_rank, psg_stream_stats *stats) {
   PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
-  PSG_REQUIRE((flags & ~PSG_GAP_UNINITIALIZED) == 0, "psg_stream_gap_ex: unknown flag");
-  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, nullptr, nullptr,
-                     (flags & PSG_GAP_UNINITIALIZED) != 0);
+  PSG_REQUIRE((flags & ~(PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED)) == 0, "psg_stream_gap_ex: unknown flag");
+  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, (flags & PSG_GAP_UNINITIALIZED) != 0,
+                              (flags & PSG_FAIL_IF_UNRESOLVED) != 0, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
+}
+extern "C" int psg_stream_gap_args(const psg_stream_args *a, int64_t *h_final_rank, psg_stream_stats *stats) {
+  PSG_REQUIRE(a && a->d_gap, "psg_stream_gap_args: arguments and gap array required");
+  PSG_REQUIRE((a->flags & ~(PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED)) == 0, "psg_stream_gap_args: unknown flag");
+  PSG_REQUIRE(!a->search || (a->tail_begin_abs >= 0 && a->tail_begin_abs + a->tail_len + a->right_context <= a->search->n),
+              "psg_stream_gap_args: the tail lies outside the text of the search context");
+  return stream_impl(PassArgs{a->rank, a->block_i0, a->block_last_symbol, a->d_tail, a->tail_len, a->right_context, a->d_gt_in, a->rank_at_context_end,
+                              a->d_gap, a->d_gt_out, a->max_chains, (a->flags & PSG_GAP_UNINITIALIZED) != 0, (a->flags & PSG_FAIL_IF_UNRESOLVED) != 0,
+                              a->search, a->tail_begin_abs, nullptr, nullptr}, h_final_rank, stats);
 }
 
 // same pass, but the ranks are handed back as a log (one u32 per streamed suffix, 0xFFFFFFFF =
@@ -986,32 +1013,33 @@ extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym,
   PSG_REQUIRE(d_log && nlog, "psg_stream_gap_log: output pointers required");
   PSG_REQUIRE(r && r->m < 0xFFFFFFFFll, "psg_stream_gap_log: block too large for a 32-bit rank log");
   *d_log = nullptr; *nlog = 0;
-  return stream_impl(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, h_final_rank, stats, d_log, nlog, false);
+  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, false, false, nullptr, 0, d_log, nlog}, h_final_rank, stats);
 }
-
-static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
-                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh);
 
 // A pass over a long tail is cut into chunks of at most 2^31 suffixes, streamed right to left with
 // the exact hand-over rank: bounds the rank log (8 + 8 GiB) and keeps every chunk in rank-log mode.
 #define PSG_PASS_CHUNK ((int64_t)1 << 31)
-static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
-                       const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                       int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh) {
+static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats) {
   int64_t chunk = PSG_PASS_CHUNK;
   if (const char *e = getenv("PSG_PASS_CHUNK")) { int64_t v = atoll(e); if (v >= 64) chunk = v / 64 * 64; }   // tests
-  if (log_out || T <= chunk)
-    return stream_chunk(r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, h_final_rank, stats, log_out, nlog_out, fresh);
+  const i64 T = A.T;
+  if (A.log_out || T <= chunk) return stream_chunk(A, h_final_rank, stats);
   psg_stream_stats acc = {};
-  int64_t fin = rank_at_end;
+  int64_t fin = A.rank_at_end;
   for (int64_t u_lo = 0; u_lo < T; u_lo += chunk) {     // u = distance from the tail end
     int64_t u_hi = std::min<int64_t>(T, u_lo + chunk);
     psg_stream_stats st = {};
     // first chunk: the caller's context / start rank; later chunks start exactly where the previous one ended
-    int rc = stream_chunk(r, i0, last_sym, d_tail + (T - u_hi), u_hi - u_lo, u_lo == 0 ? ctx : 0,
-                          d_gt_in ? d_gt_in + ((u_lo + (u_lo == 0 ? 0 : ctx)) >> 5) : nullptr, u_lo == 0 ? rank_at_end : fin, d_gap,
-                          d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr, max_chains, &fin, &st, nullptr, nullptr, fresh && u_lo == 0);
+    PassArgs C = A;
+    C.d_tail = A.d_tail + (T - u_hi);
+    C.T = u_hi - u_lo;
+    C.ctx = u_lo == 0 ? A.ctx : 0;
+    C.d_gt_in = A.d_gt_in ? A.d_gt_in + ((u_lo + (u_lo == 0 ? 0 : A.ctx)) >> 5) : nullptr;
+    C.rank_at_end = u_lo == 0 ? A.rank_at_end : fin;
+    C.d_gt_out = A.d_gt_out ? A.d_gt_out + (u_lo >> 5) : nullptr;
+    C.fresh = A.fresh && u_lo == 0;
+    C.tail_begin_abs = A.tail_begin_abs + (T - u_hi);
+    int rc = stream_chunk(C, &fin, &st);
     if (rc) return rc;
     acc.n_chains = std::max(acc.n_chains, st.n_chains); acc.chain_len = st.chain_len;
     acc.warmup_steps = std::max(acc.warmup_steps, st.warmup_steps);
@@ -1024,9 +1052,15 @@ static int stream_impl(const psg_rank_t *r, int64_t i0, int last_sym, const uint
   return 0;
 }
 
-static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T, int64_t ctx,
-                        const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap, uint32_t *d_gt_out, int64_t max_chains,
-                        int64_t *h_final_rank, psg_stream_stats *stats, uint32_t **log_out, int64_t *nlog_out, bool fresh) {
+static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats) {
+  const psg_rank_t *r = A.r;
+  const i64 i0 = A.i0, T = A.T, ctx = A.ctx, rank_at_end = A.rank_at_end;
+  const int last_sym = A.last_sym;
+  const u8 *d_tail = A.d_tail;
+  const u32 *d_gt_in = A.d_gt_in;
+  u32 *d_gap = A.d_gap, *d_gt_out = A.d_gt_out;
+  u32 **log_out = A.log_out;
+  const bool fresh = A.fresh;
   PSG_REQUIRE(ctx >= 0 && (ctx & 63) == 0, "psg_stream_gap_ctx: right context must be a multiple of 64");
   PSG_REQUIRE(r && (d_gap || log_out), "psg_stream_gap: rank and gap required");
   PSG_REQUIRE(T >= 0 && i0 >= 0 && i0 < r->m && last_sym >= 0 && last_sym < 256, "psg_stream_gap: bad scalar argument");
@@ -1045,8 +1079,8 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   for (int c = 0; c < 256; ++c) { i64 t = r->count[c] + (c == last_sym) - (c == 0); C[c] = s; s += t; }
   DevBuf T1, tot;
   if (int rc = make_tables(r, C, T1, tot)) return rc;
-  // gap update mode: log + histogram needs ranks that fit u32 and enough work to pay for the sort
-  int mode = T >= 0xFFFFFFFFll ? 1 : 0;
+  // gap update mode: log + histogram needs enough work to pay for the partition
+  int mode = 0;
   {
     const char *e = getenv("PSG_GAP_MODE");   // "atomic" | "log" | unset = auto
     bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
@@ -1060,7 +1094,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
   // pass time: every chain has the same length)
   const int cpl = chains_per_lane(r);
-  i64 Ktarget = max_chains;
+  i64 Ktarget = A.max_chains;
   if (Ktarget <= 0) {
     int blocks = 0, dev = 0, cus = 256;
     DISPATCH_LAYOUT(r, query_occupancy, r, mode, cpl, &blocks);
@@ -1070,40 +1104,82 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
     if (blocks > 8) blocks = 8;
     Ktarget = (i64)blocks * cus * PSG_WG * cpl;
   }
-  i64 L = cdiv(cdiv(T, Ktarget), 128) * 128;   // multiple of 128: a chain's gt_out words start on a 16-byte boundary
-  i64 K = cdiv(T, L);
-  st.n_chains = K; st.chain_len = L;
   DevBuf lo_d, hi_d, fin_d, list_d, flag_d;
-  int rc;
-  if ((rc = lo_d.alloc(K * 8)) || (rc = hi_d.alloc(K * 8)) || (rc = fin_d.alloc(K * 8)) || (rc = list_d.alloc(K * 8)) || (rc = flag_d.alloc(4))) return rc;
-  PSG_HIP(hipMemsetAsync(flag_d.p, 0, 4, stream()));
-  // pinned host mirrors: read-backs into pageable memory go through a slow staging path
-  i64 *lo = (i64 *)pinned_buf(0, (size_t)K * 8), *hi = (i64 *)pinned_buf(1, (size_t)K * 8), *fin = (i64 *)pinned_buf(2, (size_t)K * 8);
-  if (!lo || !hi || !fin) { set_error("stream: pinned host allocation failed"); return PSG_ENOMEM; }
-  for (i64 k = 0; k < K; ++k) fin[k] = -1;
+  i64 *lo = nullptr, *hi = nullptr, *fin = nullptr;
   std::vector<i64> list;
-  std::vector<char> resolved(K, 0);
-  WarmParams WP{d_tail, T + ctx, ctx, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
-  // warm-up with growing W for the chains that did not resolve
-  i64 nun = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    DISPATCH_LAYOUT(r, launch_warm, r, WP);
-    PSG_HIP(hipGetLastError());
-    PSG_HIP(hipMemcpyAsync(lo, lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(hipMemcpyAsync(hi, hi_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
-    PSG_HIP(psg::sync_stream());
-    list.clear();
-    for (i64 k = 0; k < K; ++k) { resolved[k] = lo[k] == hi[k]; if (!resolved[k]) list.push_back(k); }
-    st.warmup_steps = WP.W;
-    nun = (i64)list.size();
-    if (nun == 0) break;
-    WP.W *= 16;
-    WP.nitems = nun;
-    WP.list = list_d.as<i64>();
-    if (int rc_ = psg::copy_h2d(list_d.p, list.data(), (size_t)(nun * 8))) return rc_;
-    PSG_HIP(psg::sync_stream());
+  std::vector<char> resolved;
+  i64 L = 0, K = 0, nun = 0;
+  int rc;
+  // plan + warm-up; a text on which most chain starts stay open (periodic, long runs) is re-planned ONCE with few,
+  // long chains: the search then resolves a few thousand starts instead of hundreds of thousands, and the
+  // latency-bound stream kernel still runs thousands of chains side by side
+  for (int plan = 0; plan < 2; ++plan) {
+    L = cdiv(cdiv(T, Ktarget), 128) * 128;   // multiple of 128: a chain's gt_out words start on a 16-byte boundary
+    K = cdiv(T, L);
+    st.n_chains = K; st.chain_len = L;
+    if ((rc = lo_d.alloc(K * 8)) || (rc = hi_d.alloc(K * 8)) || (rc = fin_d.alloc(K * 8)) || (rc = list_d.alloc(K * 8)) || (rc = flag_d.alloc(4))) return rc;
+    PSG_HIP(hipMemsetAsync(flag_d.p, 0, 4, stream()));
+    // pinned host mirrors: read-backs into pageable memory go through a slow staging path
+    lo = (i64 *)pinned_buf(0, (size_t)K * 8); hi = (i64 *)pinned_buf(1, (size_t)K * 8); fin = (i64 *)pinned_buf(2, (size_t)K * 8);
+    if (!lo || !hi || !fin) { set_error("stream: pinned host allocation failed"); return PSG_ENOMEM; }
+    for (i64 k = 0; k < K; ++k) fin[k] = -1;
+    resolved.assign((size_t)K, 0);
+    WarmParams WP{d_tail, T + ctx, ctx, d_gt_in, i0, (u32)last_sym, L, 32, r->m, rank_at_end, K, nullptr, lo_d.as<i64>(), hi_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb};
+    // warm-up with growing W for the chains that did not resolve; with a search context (or a caller that will come
+    // back with one) two attempts suffice: a search costs about as much as a few hundred warm-up steps
+    const int attempts = (A.search || A.fail_if_unresolved) ? 2 : 4;
+    nun = 0;
+    for (int attempt = 0; attempt < attempts; ++attempt) {
+      DISPATCH_LAYOUT(r, launch_warm, r, WP);
+      PSG_HIP(hipGetLastError());
+      PSG_HIP(hipMemcpyAsync(lo, lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+      PSG_HIP(hipMemcpyAsync(hi, hi_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
+      PSG_HIP(psg::sync_stream());
+      list.clear();
+      for (i64 k = 0; k < K; ++k) { resolved[k] = lo[k] == hi[k]; if (!resolved[k]) list.push_back(k); }
+      st.warmup_steps = WP.W;
+      nun = (i64)list.size();
+      if (nun == 0) break;
+      WP.W *= 16;
+      WP.nitems = nun;
+      WP.list = list_d.as<i64>();
+      if (int rc_ = psg::copy_h2d(list_d.p, list.data(), (size_t)(nun * 8))) return rc_;
+      PSG_HIP(psg::sync_stream());
+    }
+    const i64 few = 16384;
+    if (plan == 0 && A.max_chains <= 0 && nun > K / 4 && K > few) { Ktarget = few; continue; }
+    break;
   }
   st.unresolved = nun;
+  if (nun > 0 && A.search) {
+    // K8: the open chain starts by string search.  Chain k starts at text position tail_end - k * L.
+    const i64 tail_end_abs = A.tail_begin_abs + T;
+    i64 *pos = (i64 *)pinned_buf(5, (size_t)nun * 8), *rk = (i64 *)pinned_buf(6, (size_t)nun * 8);
+    if (!pos || !rk) { set_error("stream: pinned host allocation failed"); return PSG_ENOMEM; }
+    for (i64 q = 0; q < nun; ++q) pos[q] = tail_end_abs - list[(size_t)q] * L;
+    DevBuf pos_d, rk_d;
+    if ((rc = pos_d.alloc(nun * 8)) || (rc = rk_d.alloc(nun * 8))) return rc;
+    PSG_HIP(hipMemcpyAsync(pos_d.p, pos, nun * 8, hipMemcpyHostToDevice, stream()));
+    if ((rc = psg::search_ranks_launch(A.search, pos_d.as<i64>(), nun, rk_d.as<i64>()))) return rc;
+    PSG_HIP(hipMemcpyAsync(rk, rk_d.p, nun * 8, hipMemcpyDeviceToHost, stream()));
+    PSG_HIP(psg::sync_stream());
+    for (i64 q = 0; q < nun; ++q) {
+      const i64 k = list[(size_t)q];
+      if (rk[q] < lo[k] || rk[q] > hi[k]) {   // the warm-up interval always contains the true rank
+        set_error("stream: searched start rank of chain " + std::to_string(k) + " (" + std::to_string(rk[q]) + ") lies outside its warm-up interval [" +
+                  std::to_string(lo[k]) + ", " + std::to_string(hi[k]) + "]");
+        return PSG_ECHECK;
+      }
+      lo[k] = hi[k] = rk[q];
+      resolved[k] = 1;
+    }
+    PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));
+    nun = 0;
+  }
+  if (nun > 0 && A.fail_if_unresolved) {
+    set_error("stream: " + std::to_string(nun) + " of " + std::to_string(K) + " chain starts not determined by the warm-up (pass a search context)");
+    return PSG_EUNRESOLVED;
+  }
   if (!resolved[0]) { set_error("stream: start rank of the first chain not determined inside the right context (text too repetitive for this context length)"); return PSG_ECHECK; }
   DevBuf log_d, loghi_d;
   if (mode >= 2) {
@@ -1118,7 +1194,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   // Host work per round is proportional to the chains of that round (a text whose chains all wait for their
   // right neighbour runs K rounds of one chain: scanning all K chains per round would be quadratic).
   std::vector<i64> ready, next, need;
-  const bool all_first = nun == 0;   // the usual case: every start rank came out of the warm-up
+  const bool all_first = nun == 0;   // the usual case: every start rank came out of the warm-up (or the search)
   if (!all_first)
     for (i64 k = 0; k < K; ++k) if (resolved[k]) ready.push_back(k);
   const i64 SMALL = 256;             // up to this many values are moved one by one instead of as whole arrays
@@ -1167,7 +1243,7 @@ static int stream_chunk(const psg_rank_t *r, int64_t i0, int last_sym, const uin
   double hist_ms = 0;
   if (mode == 2 && log_out) {       // hand the log to the caller (ownership moves; psg_free)
     *log_out = log_d.as<u32>();
-    *nlog_out = K * L;
+    *A.nlog_out = K * L;
     log_d.p = nullptr;
   } else if (mode == 2) {
     if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh))) return rc;

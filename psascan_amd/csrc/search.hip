@@ -1,0 +1,133 @@
+// search.hip -- K8: exact ranks of tail suffixes among the suffixes of a block by string search over the block's
+// partial suffix arrays.  Semantics of em_compute_initial_ranks (em_compute_initial_ranks.hpp:222-319): for a text
+// position p, |{s in block : text[s..n) < text[p..n)}|; a comparison that reaches the end of the block is decided
+// by the gt bit of the position the pattern has reached (lcp_compare, em_compute_initial_ranks.hpp:54-76).
+//
+// GPU form: one wavefront per position.  The 64 lanes compare 512 symbols per step (8 per lane, unaligned 8-byte
+// loads, ballot for the first mismatch); the binary search keeps the common prefix lengths with both bounds
+// (Manber-Myers), so the symbols of a long shared prefix are compared about once per position and not once per
+// probe.  This replaces the serial hand-over rounds of the chain scheme for every chain whose warm-up interval
+// does not close (text with repeats longer than the warm-up).
+#include "dev_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+using namespace psg;
+
+struct SearchPart { i64 beg, size; const u32 *lo; const u8 *hi; };
+struct SearchParams {
+  const u8 *text;
+  i64 n, cmp_end;
+  const u32 *gt;            // bit (n - j) = [text[j..n) > text[cmp_end..n)], j in (cmp_end, n]; null when cmp_end == n
+  SearchPart part[2];
+  int nparts;
+  const i64 *pos;
+  i64 npos;
+  i64 *rank;
+};
+
+__device__ __forceinline__ u64 load8_unaligned(const u8 *p) {
+  u64 v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+// [text[s..n) < text[p..n)] for s < cmp_end <= ... and p > s, comparing from offset k on (the first k symbols are
+// known to be equal).  lcp_out: symbols found equal (a lower bound of the true lcp when a gt bit decides).
+// All lanes of the wave call this with the same arguments and get the same result.
+__device__ __forceinline__ bool suffix_less_wave(const SearchParams &P, i64 s, i64 p, i64 k, i64 &lcp_out) {
+  const int lane = (int)lane_id();
+  // the known common prefix may reach beyond the end of the block for THIS suffix (it was measured on suffixes that
+  // start further left): the decision point is the block end, where the gt bit of position p + (cmp_end - s) applies
+  k = std::min(k, P.cmp_end - s);
+  for (;;) {
+    const i64 rem_p = P.n - (p + k), rem_s = P.cmp_end - (s + k);
+    if (rem_p <= 0) { lcp_out = k; return false; }          // the pattern suffix is a proper prefix: it is the smaller one
+    if (rem_s <= 0) {                                       // reached the end of the block: text[cmp_end..) against text[p+k..)
+      const i64 idx = P.n - (p + k);
+      const bool g = P.gt ? ((gload(P.gt + (idx >> 5)) >> (idx & 31)) & 1u) : false;
+      lcp_out = k;
+      return g;
+    }
+    const i64 chunk = std::min<i64>(512, std::min(rem_p, rem_s));
+    const i64 off = (i64)lane * 8;
+    u64 a = 0, b = 0;
+    if (off + 8 <= chunk) { a = load8_unaligned(P.text + s + k + off); b = load8_unaligned(P.text + p + k + off); }
+    else if (off < chunk) {
+      for (int q = 0; q < (int)(chunk - off); ++q) { a |= (u64)P.text[s + k + off + q] << (8 * q); b |= (u64)P.text[p + k + off + q] << (8 * q); }
+    }
+    const u64 x = a ^ b;
+    const u64 mism = __ballot(x != 0);
+    if (mism) {
+      const int f = __ffsll((long long)mism) - 1;
+      const u64 xa = __shfl(a, f, 64), xb = __shfl(b, f, 64);
+      const u64 xx = xa ^ xb;
+      const int byte = (__ffsll((long long)xx) - 1) >> 3;
+      lcp_out = k + (i64)f * 8 + byte;
+      return ((xa >> (8 * byte)) & 255u) < ((xb >> (8 * byte)) & 255u);
+    }
+    k += chunk;
+  }
+}
+
+// one wave per position; 4 positions per workgroup
+__global__ __launch_bounds__(PSG_WG) void search_kernel(SearchParams P) {
+  const i64 w = (i64)blockIdx.x * (PSG_WG / 64) + (threadIdx.x >> 6);
+  if (w >= P.npos) return;
+  const i64 p = P.pos[w];
+  i64 total = 0;
+  if (p < P.n) {
+    for (int t = 0; t < P.nparts; ++t) {
+      const SearchPart S = P.part[t];
+      i64 lo = 0, hi = S.size, llcp = 0, rlcp = 0;     // suffixes [0, lo) are smaller than the pattern, [hi, size) are not
+      while (lo < hi) {
+        const i64 md = lo + ((hi - lo) >> 1);
+        const i64 s = S.beg + (i64)gload(S.lo + md) + (S.hi ? (i64)gload(S.hi + md) << 32 : 0);
+        i64 l;
+        const bool less = suffix_less_wave(P, s, p, std::min(llcp, rlcp), l);
+        if (less) { lo = md + 1; llcp = l; } else { hi = md; rlcp = l; }
+      }
+      total += lo;
+    }
+  }
+  if (lane_id() == 0) P.rank[w] = total;
+}
+
+namespace psg {
+// enqueue the search for npos device-resident positions; ranks land in d_rank
+int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank) {
+  PSG_REQUIRE(sc && sc->d_text && sc->n > 0 && sc->cmp_end > 0 && sc->cmp_end <= sc->n && sc->nparts >= 1 && sc->nparts <= 2,
+              "search context: text, comparison end and 1-2 parts required");
+  PSG_REQUIRE(sc->cmp_end == sc->n || sc->d_gt_cmp_end, "search context: gt bits w.r.t. the comparison end required");
+  SearchParams P{};
+  P.text = sc->d_text; P.n = sc->n; P.cmp_end = sc->cmp_end; P.gt = sc->cmp_end == sc->n ? nullptr : sc->d_gt_cmp_end;
+  P.nparts = sc->nparts;
+  for (int t = 0; t < sc->nparts; ++t) {
+    PSG_REQUIRE(sc->part[t].d_psa_lo && sc->part[t].size >= 1 && sc->part[t].beg >= 0 && sc->part[t].beg + sc->part[t].size <= sc->cmp_end,
+                "search context: bad part");
+    P.part[t] = SearchPart{sc->part[t].beg, sc->part[t].size, sc->part[t].d_psa_lo, sc->part[t].d_psa_hi};
+  }
+  P.pos = d_pos; P.npos = npos; P.rank = d_rank;
+  if (npos == 0) return 0;
+  hipLaunchKernelGGL(search_kernel, dim3((unsigned)cdiv(npos, PSG_WG / 64)), dim3(PSG_WG), 0, stream(), P);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace psg
+
+extern "C" int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_positions, int64_t count, int64_t *h_ranks) {
+  PSG_REQUIRE(h_positions && h_ranks && count >= 0, "psg_initial_ranks");
+  if (count == 0) return 0;
+  for (i64 k = 0; k < count; ++k) PSG_REQUIRE(h_positions[k] >= 0 && h_positions[k] <= sc->n, "psg_initial_ranks: position out of range");
+  DevBuf pos, rk;
+  int rc;
+  if ((rc = pos.alloc(count * 8)) || (rc = rk.alloc(count * 8))) return rc;
+  if ((rc = psg::copy_h2d(pos.p, h_positions, (size_t)count * 8))) return rc;
+  EventTimer tm; tm.start();
+  if ((rc = psg::search_ranks_launch(sc, pos.as<i64>(), count, rk.as<i64>()))) return rc;
+  tm.stop();
+  if ((rc = psg::copy_d2h(h_ranks, rk.p, (size_t)count * 8))) return rc;
+  note_kernel_ms(tm.ms());
+  return 0;
+}

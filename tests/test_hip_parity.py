@@ -306,6 +306,91 @@ def test_stream_gap_wide_log_chunked_block_layout(A, monkeypatch):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+# ------------------------------------------------------------------ K8: start ranks by string search (a14)
+def _gt_cmp_end_bits(isa, n, e):
+    """bit (n - j) = [text[j..) > text[e..)] for j in (e, n]; bit 0 (j = n) = 0"""
+    bits = np.zeros(n - e + 1, np.uint8)
+    for j in range(e + 1, n):
+        bits[n - j] = isa[j] > isa[e]
+    return orc.packbits(list(bits) + [0] * 64)
+
+
+@pytest.mark.parametrize("kind", KINDS + ["runs"])
+def test_initial_ranks_vs_definition(A, kind):
+    """psg_initial_ranks against the definition: one part and two parts, positions all over the tail,
+    the end of the text included; periodic texts make every comparison run to the block end (gt bits decide)."""
+    n = 6000
+    if kind == "runs":
+        rng = np.random.default_rng(8)
+        t = np.repeat(rng.integers(0, 3, 400, dtype=np.uint8), rng.integers(1, 60, 400))[:n].copy()
+        n = len(t)
+    else:
+        t = make_text(kind, n, 12)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, mid, e = n // 10, n // 10 + n // 5, n // 10 + n // 2
+    d_text = A.upload(t, pad_to=16)
+    psaL, _, _, _ = orc.partial_sa(t, sa, isa, b, mid)
+    psaR, _, _, _ = orc.partial_sa(t, sa, isa, mid, e)
+    dL, dR = A.upload(psaL.astype(np.uint32)), A.upload(psaR.astype(np.uint32))
+    gt = A.upload(_gt_cmp_end_bits(isa, n, e), pad_to=8)
+    rng = np.random.default_rng(1)
+    pos = np.concatenate([[e, e + 1, n - 1, n], rng.integers(e, n + 1, 400)]).astype(np.int64)
+    rank_of = lambda p, lo, hi: int((isa[lo:hi] < (isa[p] if p < n else -1)).sum())
+    # pass B shape: both halves
+    sc = A.search_ctx(d_text, n, e, gt, [(b, mid - b, dL, None), (mid, e - mid, dR, None)])
+    assert np.array_equal(A.initial_ranks(sc, pos), [rank_of(p, b, e) for p in pos])
+    # pass A shape: the left half only, comparisons still run to e; positions from mid on
+    posA = np.concatenate([[mid, mid + 1, e], rng.integers(mid, n + 1, 300)]).astype(np.int64)
+    scA = A.search_ctx(d_text, n, e, gt, [(b, mid - b, dL, None)])
+    assert np.array_equal(A.initial_ranks(scA, posA), [rank_of(p, b, mid) for p in posA])
+    # last block: comparisons run to the end of the text, no gt bits
+    psaZ, _, _, _ = orc.partial_sa(t, sa, isa, e, n - 100)
+    scZ = A.search_ctx(d_text, n, n, None, [(e, n - 100 - e, A.upload(psaZ.astype(np.uint32)), None)])
+    posZ = np.arange(n - 100, n + 1).astype(np.int64)
+    assert np.array_equal(A.initial_ranks(scZ, posZ), [rank_of(p, e, n - 100) for p in posZ])
+
+
+@pytest.mark.parametrize("kind", ["alla", "per3", "fib", "zeros", "repeats"])
+@pytest.mark.parametrize("mode", ["atomic", "log"])
+def test_stream_gap_repetitive_text_resolves_in_one_round(A, monkeypatch, kind, mode):
+    """Text whose chain starts the warm-up cannot determine (periodic text; English with injected long repeats):
+    with a search context every start rank comes from the string search and the pass is ONE kernel launch
+    (was: one launch per chain).  Without one, PSG_FAIL_IF_UNRESOLVED reports it instead of serialising."""
+    from psascan_amd._lib import PsgError
+    monkeypatch.setenv("PSG_GAP_MODE", mode)
+    n = 40000
+    if kind == "repeats":
+        rng = np.random.default_rng(4)
+        t = rng.integers(97, 105, n, dtype=np.uint8)
+        rep = t[1000:9000].copy()                       # an 8000-symbol repeat: in the block and twice in the tail
+        t[22000:30000] = rep
+        t[31000:39000] = rep
+    else:
+        t = make_text(kind, n, 2)
+    b, e = 500, 500 + n // 3
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    m, T = e - b, n - e
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e)
+    sc = A.search_ctx(d_text, n, e, A.upload(_gt_cmp_end_bits(isa, n, e), pad_to=8), [(b, m, A.upload(psa.astype(np.uint32)), None)])
+    d_gap = A.zeros(4 * (m + 2))
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    with pytest.raises(PsgError) as ei:
+        A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 96, fail_if_unresolved=True)
+    assert ei.value.code == A.PSG_EUNRESOLVED
+    A.lib().psg_memset(d_gap.ptr, 0, d_gap.nbytes)
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 96, search=sc, tail_begin_abs=e)
+    assert st.unresolved > 0 and st.rounds == 1 and st.n_chains > 32
+    assert fin == want_fin
+    assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
 def test_device_allocator_arena(A, gpu_lib):
     """psg_malloc/psg_free go through the arena of runtime.hip (best fit, split, coalesce for blocks >= 1 MiB,
     size classes below): live blocks never overlap, whatever the order of frees and the mix of sizes."""
