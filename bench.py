@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path throughput of the MI355X-native pSAscan path.
+"""bench.py -- throughput of the MI355X-native pSAscan hot path.
 
-Workload (BASELINE.json configs[1], scaled by --gib): one text block of uniform random bytes
-0..254 cut into two half-blocks (last-block schedule of the reference, partial_sufsort.hpp:
-86-93,418-429).  One "step" = one pass of the hot path over it with all inputs resident in HBM:
-    rank build over the left half's BWT            (new rank4n<>,          partial_sufsort.hpp:403)
-    stream the right half through it -> gap array  (compute_gap<T>,        :412-414)
-    gap array -> merge bitvector                   (convert_to_bitvector / save_to_file, :422,441)
-    merge the two partial SAs -> 5n bytes of .sa5  (merge<T>,              psascan.hpp:120-124)
-The host suffix sort of the half-blocks is NOT part of the hot path (north_star: stays on host
-cores); the bench prepares the partial SAs on the device before the timed region.
+N = 1 (default): BASELINE.json configs[2], the largest configuration one GPU holds -- 32 GiB of English-like text
+(seeded synthetic: Zipfian words over a skewed alphabet, psgx_gen_text mode 3), 8 blocks of 4 GiB = 16 half-blocks.
+One "step" = the whole block schedule of the reference's process_block / pSAscan on the GPU, right to left
+(partial_sufsort.hpp:67-551, psascan.hpp:117-125):
+    per block: rank over the left half's BWT, stream the right half (pass A), gap -> bitvector, merge the BWTs,
+               rank over the block BWT (m = 2^32), stream the whole tail (pass B, 4..28 Gi suffixes in chunks of
+               2^31), split the block gap into the half-blocks' merge bitvectors
+    final merge of the 16 partial suffix arrays into 32 Gi uint40 entries.
+Resident in HBM when the timed region starts: the text, every half-block's BWT, gt bits and i0.  The partial SAs
+(128 GiB) do NOT fit next to the pass temporaries: they wait in pinned host memory (where the host sorter of
+construct_sa leaves them) and are streamed through the device during the merge (psg_merge_stream); the .sa5
+slices are verified on the device (permutation sum + sampled adjacent pairs per slice) and dropped, so the
+timed step carries 128 GiB of H2D traffic for the PSAs and no D2H (`pcie` in the JSON line says how much; the
+rate with the 160 GiB of output copied back to the host is reported as `with_output_d2h`).  The host suffix sort of
+the half-blocks is NOT part of the hot path (north_star keeps it on host cores); the bench prepares the partial
+SAs on the device before the timed region.  `end_to_end_cli` times the whole construct_sa program on a bounded
+sample; `configs1_step` keeps last round's single-block step (4 GiB uniform bytes) as a secondary figure.
 
-N > 1 (strong scaling of the same job): every rank holds the inputs; the tail is cut into N
-ranges (the reference's own parallel axis, compute_gap.hpp:68-69), each rank streams its range
-into a rank log; the logs are split by owner of the gap slice and exchanged with ONE RCCL
-all-to-all (4 B per streamed suffix), every rank counts its slice and marks its bits, the bit
-arrays are summed with one all-reduce (n/8 bytes), the gt bits are all-gathered, and each rank
-merges 1/N of the output.
+N > 1: strong scaling of the configs[1] job with the tail-sharded pass (rank-log all-to-all), see config1().
 
 Prints ONE JSON line (rank 0).
 """
@@ -42,10 +45,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PMC_TRAFFIC_B_PER_SUFFIX = {8.3: 71.5, 16.0: 71.4}
 
 
-def end_to_end_cli(sample_mib, log):
-    """The whole construct_sa program (host/construct_sa: read the file, host SA-IS of the half-blocks on the host
-    threads, the device passes, merge, write the .sa5) on a bounded sample, as a child process.  Reported next to
-    the hot-path metric; it is bound by the host sorter, not by the GPU."""
+def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True):
+    """The whole construct_sa program (host/construct_sa: map the file, host suffix sort of the half-blocks on the
+    host threads, the device passes, streamed merge, write the .sa5) on a bounded sample, as a child process, with
+    its own device-side check of the output (--check).  It is bound by the host sorter, not by the GPU."""
     import subprocess
     import tempfile
     import numpy as np
@@ -53,19 +56,27 @@ def end_to_end_cli(sample_mib, log):
     if not os.path.exists(cli):
         return None
     threads = min(16, os.cpu_count() or 1)
+    n = sample_mib << 20
     with tempfile.TemporaryDirectory() as d:
         f = os.path.join(d, "sample.bin")
-        np.random.default_rng(11).integers(0, 255, sample_mib << 20, dtype=np.uint8).tofile(f)
+        if english and api is not None:
+            d_t = extras.gen_text(n, extras.MODE_ENGLISH, 0, seed=11)
+            api.download(d_t, np.uint8, n).tofile(f)
+            d_t.free()
+        else:
+            np.random.default_rng(11).integers(0, 255, n, dtype=np.uint8).tofile(f)
         t0 = time.time()
-        r = subprocess.run([cli, "-m", "8G", "--block-size", str(32 << 20), f], capture_output=True, text=True,
-                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=600)
+        r = subprocess.run([cli, "-m", "8G", "--block-size", str(32 << 20), "--check=1024", f], capture_output=True, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=900)
         wall = time.time() - t0
-        ok = r.returncode == 0 and os.path.getsize(f + ".sa5") == 5 * (sample_mib << 20)
+        ok = r.returncode == 0 and os.path.getsize(f + ".sa5") == 5 * n and "permutation sum ok, 0 of" in r.stderr
     if not ok:
         log("construct_sa failed:", r.stderr[-300:])
         return {"value": None, "unit": "MB/s", "sample": "failed"}
-    return {"value": (sample_mib << 20) / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2),
-            "sample": f"{sample_mib} MiB uniform bytes 0..254 from a file, 32 MiB blocks, .sa5 written to a file; wall time of the child process"}
+    peak = [l.strip() for l in r.stderr.splitlines() if "device memory" in l]
+    return {"value": n / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2), "output_check": "permutation sum ok, 0 sampled pairs out of order",
+            "device_memory": peak[0] if peak else None,
+            "sample": f"{sample_mib} MiB {'English-like text' if english else 'uniform bytes 0..254'} from a file, 32 MiB blocks, host suffix sort on {threads} threads, .sa5 written to a file; wall time of the child process"}
 
 
 def parse():
@@ -73,17 +84,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=4.0, help="text size in GiB (configs[1] = 4)")
+    ap.add_argument("--config", type=int, default=0, help="2 = configs[2] block schedule (default at 1 GPU), 1 = configs[1] single-block step (default at N > 1)")
+    ap.add_argument("--gib", type=float, default=0.0, help="text size in GiB (default: 32 for configs[2], 4 for configs[1])")
+    ap.add_argument("--block-gib", type=float, default=0.0, help="configs[2]: block size in GiB (default text/8)")
+    ap.add_argument("--text", choices=["bytes", "dna", "english"], default=None, help="alphabet of the synthetic text (default: english for configs[2], bytes for configs[1])")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] secondary figure and the CLI sample")
+    ap.add_argument("--with-output-d2h", action="store_true", help="configs[2]: also time one step with the .sa5 slices copied back to the host")
     ap.add_argument("--max-chains", type=int, default=0)
     ap.add_argument("--rank-block", type=int, default=0, help="data bytes per rank block (0=auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--text", choices=["bytes", "dna"], default="bytes", help="bytes = configs[1] (the metric's workload); dna = sigma 4 (configs[3]'s alphabet) at the same size, for DESIGN.md")
     return ap.parse_args()
 
 
-def cpu_baseline(api, extras, sample_mib, log):
+def cpu_baseline(api, extras, sample_mib, log, mode=None):
     """The reference's own compute_gap / convert_to_bitvector / merge (oracle/_ref, built from
     /root/reference where it lies) timed on this box's host cores on a bounded sample of the
     same workload.  Falls back to the C restatement (kind "port") when oracle/_ref is absent."""
@@ -93,7 +108,8 @@ def cpu_baseline(api, extras, sample_mib, log):
     import shutil
     n = sample_mib << 20
     mid = n // 2
-    d_text = extras.gen_text(n, extras.MODE_BYTES255, 0, seed=99)
+    mode = extras.MODE_BYTES255 if mode is None else mode
+    d_text = extras.gen_text(n, mode, 0, seed=99)
     Lh = extras.sort_halfblock(d_text, n, 0, mid)
     Rh = extras.sort_halfblock(d_text, n, mid, n)
     text = api.download(d_text, np.uint8, n)
@@ -160,12 +176,11 @@ def cpu_baseline(api, extras, sample_mib, log):
     for b in (d_text, Lh["bwt"], Lh["psa_lo"], Lh["gt_begin"], Rh["bwt"], Rh["psa_lo"], Rh["gt_begin"]):
         b.free()
     return {"value": n / 1e6 / total, "unit": "MB/s", "cores": cores, "kind": kind,
-            "sample": f"{sample_mib} MiB uniform bytes 0..254, two {sample_mib // 2} MiB half-blocks: rank build + stream + gap->bitvector + merge, seconds={total:.2f}",
+            "sample": f"{sample_mib} MiB {'English-like text' if mode == extras.MODE_ENGLISH else 'uniform bytes 0..254'}, two {sample_mib // 2} MiB half-blocks: rank build + stream + gap->bitvector + merge, seconds={total:.2f}",
             **detail}
 
 
-def main():
-    args = parse()
+def setup(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,11 +216,19 @@ def main():
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
-    n = int(args.gib * (1 << 30)) // 128 * 128
+    return rank, world, local, dist, torch, np, api, extras, L, log
+
+
+def config1(args, ctx, gib, steps, warmup, text_mode, with_baselines):
+    """configs[1]-shaped step: one block of two half-blocks (rank build + pass A + gap -> bitvector + merge); at
+    N > 1 the pass is sharded over the tail (rank-log all-to-all).  Returns the result dict on rank 0."""
+    rank, world, local, dist, torch, np, api, extras, L, log = ctx
+    from psascan_amd import distributed as D
+    n = int(gib * (1 << 30)) // 128 * 128
     mid = n // 2
     ls, rs = mid, n - mid
     t0 = time.time()
-    d_text = extras.gen_text(n, extras.MODE_DNA if args.text == "dna" else extras.MODE_BYTES255, 0, seed=2)
+    d_text = extras.gen_text(n, {"dna": extras.MODE_DNA, "english": extras.MODE_ENGLISH}.get(text_mode, extras.MODE_BYTES255), 0, seed=2)
     Rh = extras.sort_halfblock(d_text, n, mid, n)
     Lh = extras.sort_halfblock(d_text, n, 0, mid)
     api.sync()
@@ -214,7 +237,6 @@ def main():
     Lh["psa_hi"] = Rh["psa_hi"] = None
 
     # tail range of this rank (64-aligned cut points so gt words do not straddle ranks)
-    from psascan_amd import distributed as D      # cut logic shared with the gloo tests
     cuts = D.tail_cuts(mid, n, world)
     tb, te = cuts[rank], cuts[rank + 1]
     out_cuts = D.output_cuts(n, world)
@@ -300,11 +322,11 @@ def main():
             torch.cuda.synchronize()
         api.sync()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -330,17 +352,17 @@ def main():
 
     if rank == 0:
         st, rk_bytes = stats_last
-        K = args.steps
+        K = steps
         per = {k: v / K for k, v in times.items()}
         stream_suffixes = te - tb
         kernel_s = per["stream_kernel"]
         achieved = A_STREAM * stream_suffixes / kernel_s / 1e9 if kernel_s > 0 else 0.0
         res = {
             "metric": "input MB/s, hot path (rank build + gap-stream + gap->bitvector + merge to .sa5), inputs resident in HBM",
-            "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/u32/u40 integer", "data": "synthetic",
-            "config": {"workload": (f"configs[1]: {n / 2 ** 30:.2f} GiB uniform random bytes 0..254 (sigma=255; byte 255 is reserved by the reference)" if args.text == "bytes" else f"{n / 2 ** 30:.2f} GiB uniform random DNA (sigma=4), not the metric's workload") + f", one block = two {mid / 2 ** 30:.2f} GiB half-blocks, single pass A + merge",
+            "config": {"workload": (f"configs[1]: {n / 2 ** 30:.2f} GiB uniform random bytes 0..254 (sigma=255; byte 255 is reserved by the reference)" if text_mode == "bytes" else f"{n / 2 ** 30:.2f} GiB {text_mode} text, not configs[1]'s alphabet") + f", one block = two {mid / 2 ** 30:.2f} GiB half-blocks, single pass A + merge",
                        "text_bytes": n, "half_blocks": 2, "tail_sharding": f"dp{world}" if world > 1 else "none",
                        "chains": st.n_chains, "chain_len": st.chain_len, "rank_bytes_per_symbol": rk_bytes / ls},
             "gap_stream_suffixes_per_s": rs * 1.0 / (per["stream"] + per["comm"]) if world > 1 else stream_suffixes / per["stream"],
@@ -356,16 +378,196 @@ def main():
             "merge_roofline": {"achieved": A_MERGE * (oe - ob) / per["merge"] / 1e9, "unit": "GB/s", "note": "includes plan build (rank samples over the merge bitvector)"},
             "property_check": check,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and with_baselines and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(api, extras, args.cpu_sample_mib, log)
             except Exception as e:  # the baseline must not take the bench down
                 res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
             try:
-                res["end_to_end_cli"] = end_to_end_cli(1024, log)
+                res["end_to_end_cli"] = end_to_end_cli(1024, log, english=False)
             except Exception as e:
                 res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}
+        for b in (d_text, Lh["bwt"], Lh["psa_lo"], Lh["gt_begin"], Rh["bwt"], Rh["psa_lo"], Rh["gt_begin"], gt_out, mbv, d_out, gt_in):
+            b.free()
+        if world == 1:
+            gap_buf.free()
+        return res
+    return None
+
+
+def reference_ram_use(block, threads=16):
+    """-m that gives the reference this max_block_size with `threads` threads (psascan.hpp:73-91): the last block's
+    left half is min(block, ram_use / 10) (partial_sufsort.hpp:86-93), so the split depends on it."""
+    g = 1 << 21
+    rft = 2 * threads * g + int(0.8 * threads) * g + threads * g + threads * (6 << 20)
+    return int(block * 5.2) + rft + 8
+
+
+def config2(args, ctx, n, block):
+    """configs[2]: the whole block schedule on one GPU (see the module docstring)."""
+    rank, world, local, dist, torch, np, api, extras, L, log = ctx
+    from psascan_amd import pipeline
+    ram_use = reference_ram_use(block)
+    plan = pipeline.block_plan(n, block, ram_use)
+    mode = {"bytes": extras.MODE_BYTES255, "dna": extras.MODE_DNA, "english": extras.MODE_ENGLISH}[args.text]
+    t0 = time.time()
+    d_text = extras.gen_text(n, mode, 0, seed=3)
+    prepared, pins = {}, []
+    tsort = tpin = 0.0
+    for (b, mid, e) in plan:
+        for hb, he in ((mid, e), (b, mid)):
+            if he <= hb:
+                continue
+            t1 = time.time()
+            r = extras.sort_halfblock(d_text, n, hb, he)
+            api.sync()
+            tsort += time.time() - t1
+            init = None
+            if hb == b and e > mid:      # left half: start rank of pass A = #{s in L : text[s..) < text[e..)}, by string search
+                sc = api.search_ctx(d_text, n, n, None, [(hb, he - hb, r["psa_lo"], None)])
+                init = int(api.initial_ranks(sc, [e])[0])
+            t1 = time.time()
+            pa = api.PinnedArray(he - hb, np.uint32)            # the partial SA waits in pinned host memory
+            api.check(L.psg_d2h(pa.ptr, r["psa_lo"].ptr, 4 * (he - hb)))
+            r["psa_lo"].free()
+            tpin += time.time() - t1
+            pins.append(pa)
+            prepared[(hb, he)] = {"device": True, "psa_host": pa.array, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
+                                  "initA": init, "keep_inputs": True}
+    log(f"prepared {n / 2 ** 30:.2f} GiB {args.text} text, {len(prepared)} half-blocks in {time.time() - t0:.1f}s (device sort {tsort:.1f}s, pinned alloc + D2H {tpin:.1f}s)")
+
+    class Replay:
+        device = True
+
+        def __call__(self, text, beg, end, gt_tail):
+            return dict(prepared[(beg, end)])
+
+    want_sum = (n * (n - 1) // 2) % (1 << 64)
+    agg = {"stream_ms": 0.0, "kernel_ms": 0.0, "hist_ms": 0.0, "suffixes": 0, "launches": 0, "passes_s": 0.0, "merge_s": 0.0, "merge_kernel_ms": 0.0,
+           "h2d": 0, "d2h": 0, "stage_ms": 0.0}
+    last = {}
+
+    def step(timed, sink=None):
+        stats, tm = [], {}
+        ts = time.perf_counter()
+        ms, chk = pipeline.construct_sa5(None, block, ram_use, Replay(), args.max_chains, stats, d_text=d_text, n=n, merge="stream",
+                                         sink=sink, check_samples=4096, timings=tm)
+        api.sync()
+        te = time.perf_counter()
+        if chk != (want_sum, 0):
+            raise RuntimeError(f"output check failed: sum ok {chk[0] == want_sum}, {chk[1]} sampled adjacent pairs out of order")
+        if timed:
+            for kind, b, e, st in stats:
+                T = (e - b) - (e - b + 1) // 2 if kind == "A" else n - e
+                for (pb, pm, pe) in plan:
+                    if pb == b and kind == "A":
+                        T = pe - pm
+                agg["stream_ms"] += st.total_ms; agg["kernel_ms"] += st.kernel_ms; agg["hist_ms"] += st.hist_ms
+                agg["suffixes"] += T; agg["launches"] += st.rounds
+            agg["passes_s"] += tm["passes_done"] - ts; agg["merge_s"] += te - tm["passes_done"]
+            agg["merge_kernel_ms"] += ms.kernel_ms; agg["h2d"] += ms.h2d_bytes; agg["d2h"] += ms.d2h_bytes; agg["stage_ms"] += ms.stage_ms
+        last["stats"], last["ms"] = stats, ms
+        return te - ts
+
+    for _ in range(args.warmup):
+        step(False)
+    api.sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    api.sync()
+    elapsed = time.perf_counter() - t_start
+    K = args.steps
+    in_use, peak, reserved = api.mem_stats()
+    with_d2h = None
+    if args.with_output_d2h:
+        got = [0]
+
+        def sink(view, first, cnt):
+            got[0] += cnt
+        dt = step(False, sink)
+        with_d2h = {"value": n / 1e6 / dt, "unit": "MB/s", "seconds": round(dt, 3), "entries_received_on_host": got[0],
+                    "note": "same step with every .sa5 slice copied to pinned host memory (5 bytes per suffix over PCIe) and handed to a sink that drops it"}
+    suff, kern_s = agg["suffixes"] / K, agg["kernel_ms"] / K / 1e3
+    achieved = A_STREAM * suff / kern_s / 1e9 if kern_s > 0 else 0.0
+    rankB = [getattr(p[3], "rank_bytes", 0) / (p[2] - p[1]) for p in last["stats"] if p[0] == "B"]
+    traffic_tab = {}
+    try:
+        traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pass
+    tr = traffic_tab.get(f"configs2_{args.text}")
+    launches = agg["launches"] / K
+    res = {
+        "metric": "input MB/s, hot path of the whole block schedule (rank builds + all gap-stream passes + gap->bitvector + BWT merge + gap split + final merge to .sa5)",
+        "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u40 integer", "data": "synthetic",
+        "config": {"workload": f"configs[2]: {n / 2 ** 30:.2f} GiB {'English-like text (seeded Zipfian words, sigma=28)' if args.text == 'english' else args.text + ' text'}, "
+                               f"{len(plan)} blocks of {block / 2 ** 30:.2f} GiB = {len(prepared)} half-blocks on 1 GPU, whole schedule (passes A and B of every block + final merge)",
+                   "text_bytes": n, "blocks": len(plan), "half_blocks": len(prepared), "block_bytes": block,
+                   "resident_in_hbm": "text, BWT + gt bits of every half-block, merge bitvectors", "in_pinned_host_memory": "partial suffix arrays (4 B/symbol), streamed during the merge",
+                   "rank_bytes_per_symbol_pass_B": round(sum(rankB) / max(1, len(rankB)), 3)},
+        "gap_stream_suffixes_per_s": suff / (agg["stream_ms"] / K / 1e3),
+        "gap_stream_kernel_suffixes_per_s": suff / kern_s if kern_s else None,
+        "streamed_suffixes_per_step": suff,
+        "phase_ms": {"passes_total": round(1e3 * agg["passes_s"] / K, 1), "stream_passes": round(agg["stream_ms"] / K, 1), "stream_kernel": round(agg["kernel_ms"] / K, 1),
+                     "stream_partition_hist": round(agg["hist_ms"] / K, 1), "merge_total": round(1e3 * agg["merge_s"] / K, 1),
+                     "merge_kernels": round(agg["merge_kernel_ms"] / K, 1), "merge_host_staging": round(agg["stage_ms"] / K, 1)},
+        "pcie": {"h2d_bytes_per_step": agg["h2d"] // K, "d2h_bytes_per_step": agg["d2h"] // K,
+                 "note": "partial SAs stream in from pinned host memory during the merge; the output is checked on the device and dropped"},
+        "with_output_d2h": with_d2h,
+        "device_memory": {"peak_in_use_gib": round(peak / 2 ** 30, 2), "reserved_gib": round(reserved / 2 ** 30, 2)},
+        "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (tr["bytes_per_suffix"] * suff / launches) if tr else None,
+                     "traffic_source": (tr["source"] if tr else "no PMC pass recorded for this workload in profiles/pmc_traffic.json"),
+                     "algorithmic_bytes_per_suffix": A_STREAM, "suffixes_per_launch": suff / launches, "launches_per_step": launches,
+                     "avg_launch_ms": 1e3 * kern_s / launches,
+                     "random_access_ceiling": "profiles/r01_membench.txt: dependent random 16-byte loads (one 64 B sector each) top out at 48-51 G/s on this chip; one sector per suffix is this kernel's floor"},
+        "merge_roofline": {"achieved": A_MERGE * n / (agg["merge_s"] / K) / 1e9, "unit": "GB/s",
+                           "note": "PCIe-bound: 4 bytes per suffix of partial SA cross the link (H2D) inside the timed merge"},
+        "property_check": {"every_step": "permutation sum == n(n-1)/2 and 4096 sampled adjacent pairs per 64 Mi-entry slice in suffix order, on the device"},
+    }
+    for pa in pins:
+        pa.free()
+    for v in prepared.values():
+        v["bwt"].free(); v["gt_begin"].free()
+    d_text.free()
+    L.psg_trim()
+    return res
+
+
+def main():
+    args = parse()
+    ctx = setup(args)
+    rank, world, local, dist, torch, np, api, extras, L, log = ctx
+    cfg = args.config or (2 if world == 1 else 1)
+    if cfg == 2 and world == 1:
+        args.text = args.text or "english"
+        n = int((args.gib or 32.0) * (1 << 30)) // 4096 * 4096
+        block = int((args.block_gib * (1 << 30)) if args.block_gib else n // 8)
+        res = config2(args, ctx, n, block)
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(api, extras, args.cpu_sample_mib, log, {"english": extras.MODE_ENGLISH, "dna": extras.MODE_DNA}.get(args.text))
+            except Exception as e:  # the baseline must not take the bench down
+                res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
+        if not args.no_secondary:
+            try:
+                res["end_to_end_cli"] = end_to_end_cli(1024, log, api, extras, english=args.text == "english")
+            except Exception as e:
+                res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}
+            try:
+                c1 = config1(args, ctx, 4.0, 3, 1, "bytes", False)
+                res["configs1_step"] = {k: c1[k] for k in ("value", "unit", "ms_per_step", "phase_ms", "gap_stream_kernel_suffixes_per_s", "roofline", "property_check")}
+                res["configs1_step"]["workload"] = c1["config"]["workload"]
+            except Exception as e:
+                res["configs1_step"] = {"value": None, "note": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
+    else:
+        args.text = args.text or "bytes"
+        res = config1(args, ctx, args.gib or 4.0, args.steps, args.warmup, args.text, True)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -195,6 +195,37 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
 
+  // One streaming pass.  The chain start ranks normally come out of the warm-up on the device; on text with long
+  // repeats some stay open: the pass then reports PSG_EUNRESOLVED, the partial SAs of the block's halves are
+  // uploaded (they live in host memory) and the pass is repeated with a search context -- the open starts are
+  // found by string search over them (em_compute_initial_ranks.hpp:222-319), still in one kernel launch.
+  struct PartRef { int64_t beg, size; const std::vector<uint32_t> *lo; const std::vector<uint8_t> *hi; };
+  auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
+                         uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
+                         psg_stream_stats *st) {
+    psg_stream_args a{};
+    a.rank = rank; a.block_i0 = i0; a.block_last_symbol = last_sym; a.d_tail = d_text.as<uint8_t>() + tail_beg; a.tail_len = T; a.right_context = 0;
+    a.d_gt_in = d_gt_in; a.rank_at_context_end = rank_at_end; a.d_gap = d_gap; a.d_gt_out = d_gt_out; a.max_chains = max_chains;
+    a.flags = PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED; a.search = nullptr; a.tail_begin_abs = tail_beg;
+    int rc = psg_stream_gap_args(&a, nullptr, st);
+    if (rc == PSG_EUNRESOLVED) {
+      double t1 = wclock();
+      psg_search_ctx sc{};
+      sc.d_text = d_text.as<uint8_t>(); sc.n = n; sc.cmp_end = cmp_end; sc.d_gt_cmp_end = cmp_end == n ? nullptr : d_gt_cmp_end;
+      sc.nparts = (int)parts.size();
+      std::vector<Dev> up;
+      for (size_t k = 0; k < parts.size(); ++k) {
+        up.push_back(upload(parts[k].lo->data(), 4 * parts[k].size));
+        sc.part[k].beg = parts[k].beg; sc.part[k].size = parts[k].size; sc.part[k].d_psa_lo = up.back().as<uint32_t>(); sc.part[k].d_psa_hi = nullptr;
+        if (!parts[k].hi->empty()) { up.push_back(upload(parts[k].hi->data(), parts[k].size)); sc.part[k].d_psa_hi = up.back().as<uint8_t>(); }
+      }
+      a.flags = PSG_GAP_UNINITIALIZED; a.search = &sc;
+      rc = psg_stream_gap_args(&a, nullptr, st);
+      if (g_verbose) fprintf(stderr, "      long repeats: %ld chain starts found by string search (partial SAs uploaded, %.2fs)\n", (long)st->unresolved, wclock() - t1);
+    }
+    if (rc) throw std::runtime_error(std::string("psg_stream_gap_args: ") + psg_last_error());
+  };
+
   // ---- look-ahead sorter: all half-blocks on all host cores, right to left (the order the schedule needs them).
   // The comparisons that run past a half-block's end are decided by reading on in the text, which is in host
   // memory, instead of by the gt bits of the blocks to the right (initial_partial_sufsort.hpp:61-80) -- so a
@@ -331,8 +362,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     DoneHalfBlock hbL = keep_hb(L), hbR = keep_hb(R);
     psg_stream_stats st;
     t0 = wclock();
-    CK(psg_stream_gap_ex(rankL, L_i0, text.p[(size_t)mid - 1], d_text.as<uint8_t>() + mid, rs, 0, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(),
-                         gtA.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
+    stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
+                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi}}, &st);
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankL);
@@ -365,8 +396,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t T = n - e;
     Dev gapB(4 * (bs + 2), false);
     t0 = wclock();
-    CK(psg_stream_gap_ex(rankB, block_i0, text.p[(size_t)e - 1], d_text.as<uint8_t>() + e, T, 0, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(),
-                         gt_new.as<uint32_t>(), max_chains, PSG_GAP_UNINITIALIZED, nullptr, &st));
+    stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(), gt_new.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
+                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi}}, &st);
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankB);

@@ -66,23 +66,34 @@ class _GtReader:
         return self.fn(v)
 
 
-def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=None, d_text=None, return_device=False):
+def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=None, d_text=None, return_device=False,
+                  n=None, merge="device", slice_entries=64 << 20, sink=None, check_samples=None, timings=None):
     """Whole run on one GPU.  Returns the .sa5 bytes (np.uint8, 5n), or the device buffer holding them.
     A sorter may return device-resident results ({"device": True, "psa_lo", "bwt", "gt_begin": DeviceBuffers,
-    "i0", "size"}), e.g. psascan_amd.extras.sort_halfblock for the full-size property tests."""
-    text = np.ascontiguousarray(text, np.uint8)
-    n = len(text)
+    "i0", "size"}), e.g. psascan_amd.extras.sort_halfblock for the full-size property tests; with "psa_host" (a
+    uint32 numpy array, ideally pinned) instead of "psa_lo" the partial SA stays in host memory.
+    text=None: device-only flow (d_text and n given; no host copy of the text is made).
+    merge="stream": the final merge streams the partial SAs from host memory (psg_merge_stream) and hands the
+    output to `sink` (None = dropped); returns (merge stats, (sum, bad_pairs) or None)."""
+    if text is not None:
+        text = np.ascontiguousarray(text, np.uint8)
+        n = len(text)
     if n == 0:
         return np.zeros(0, np.uint8)
-    tb = text.tobytes()
+    tb = None
     if d_text is None:
         d_text = api.upload(text, pad_to=16)
+
+    def sym(pos):                      # text[pos]
+        return int(text[pos]) if text is not None else int(api.download(d_text, np.uint8, 1, pos)[0])
+
     host_sorter = not getattr(sorter, "device", False)
     gt_words = (n + 31) // 32 + 2
     gt_cur = api.zeros(4 * gt_words)   # gt w.r.t. current block begin; bit idx = n - j
     gt_new = api.zeros(4 * gt_words)
     half_blocks = []
     keep = []
+    import time as _time
 
     def dev(res, key, pad):
         """device buffer of a sorter result field (uploads host arrays)"""
@@ -92,17 +103,30 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         return api.upload(a[: (res["_bits"] + 7) // 8] if key == "gt_begin" else a, pad_to=pad)
 
     def host_psa(res):
+        if res.get("psa_host") is not None:
+            return res["psa_host"]
         if res.get("device"):
             return api.download(res["psa_lo"], np.uint32, res["size"])
         return res["psa"]
 
     def up_hb(beg, res):
+        if res.get("psa_host") is not None:
+            return {"beg": beg, "size": res["size"], "psa_lo": res["psa_host"], "psa_hi": None, "mbv": None, "dev_psa": None}
         if res.get("device"):
-            return {"beg": beg, "size": res["size"], "psa_lo": res["psa_lo"], "psa_hi": None, "mbv": None}
+            return {"beg": beg, "size": res["size"], "psa_lo": res["psa_lo"], "psa_hi": None, "mbv": None, "dev_psa": res["psa_lo"]}
         psa = np.asarray(res["psa"], np.uint64)
+        if merge == "stream":
+            hi = (psa >> np.uint64(32)).astype(np.uint8) if len(psa) and int(psa.max()) >> 32 else None
+            return {"beg": beg, "size": len(psa), "psa_lo": (psa & np.uint64(0xFFFFFFFF)).astype(np.uint32), "psa_hi": hi, "mbv": None, "dev_psa": None}
         d_lo = api.upload((psa & np.uint64(0xFFFFFFFF)).astype(np.uint32))
         d_hi = api.upload((psa >> np.uint64(32)).astype(np.uint8)) if len(psa) and int(psa.max()) >> 32 else None
-        return {"beg": beg, "size": len(psa), "psa_lo": d_lo, "psa_hi": d_hi, "mbv": None}
+        return {"beg": beg, "size": len(psa), "psa_lo": d_lo, "psa_hi": d_hi, "mbv": None, "dev_psa": d_lo if d_hi is None else None}
+
+    def search_for(e, parts):
+        """search context of a pass when every part's partial SA is on the device (chain starts on repetitive text)"""
+        if any(p["dev_psa"] is None for p in parts):
+            return None
+        return api.search_ctx(d_text, n, e, gt_cur if e < n else None, [(p["beg"], p["size"], p["dev_psa"], None) for p in parts])
 
     for (b, mid, e) in block_plan(n, max_block_size, ram_use):
         ls, rs, bs = mid - b, e - mid, e - b
@@ -164,12 +188,22 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
             continue
         hbR = up_hb(mid, R)
         d_lbwt = dev(L, "bwt", 16)
+        last_left, last_block_sym = sym(mid - 1), sym(e - 1)
         # ---- step 3: pass A, right half streamed through rank(left BWT) (:403-414)
         rankL = api.rank_build(d_lbwt, ls)
         gapA = api.DeviceBuffer(4 * (ls + 2))     # fresh gap array: the pass zero-fills / overwrites it
         gtA = api.zeros(4 * ((rs + 31) // 32 + 1))
-        initA = rank_by_search(tb, b, host_psa(L), e)
-        _, stA = api.stream_gap(rankL, L["i0"], text[mid - 1], d_text.at(mid), rs, d_rgt, initA, gapA, gtA, max_chains, fresh_gap=True)
+        scA = search_for(e, [hbL])
+        if L.get("initA") is not None:
+            initA = L["initA"]
+        elif scA is not None:
+            initA = int(api.initial_ranks(scA, [e])[0])
+        else:
+            if tb is None:
+                tb = text.tobytes()
+            initA = rank_by_search(tb, b, host_psa(L), e)
+        _, stA = api.stream_gap(rankL, L["i0"], last_left, d_text.at(mid), rs, d_rgt, initA, gapA, gtA, max_chains, fresh_gap=True,
+                                search=scA, tail_begin_abs=mid)
         rankL.free()
         if stats is not None:
             stats.append(("A", b, e, stA))
@@ -186,17 +220,20 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
             continue
         # ---- step 4: BWT merge (:468-471)
         d_bbwt = api.DeviceBuffer(bs + 16)
-        block_i0 = api.merge_bwt(d_lbwt, d_rbwt, ls, rs, L["i0"], R["i0"], text[mid - 1], bvA, d_bbwt)
-        d_lbwt.free(); d_rbwt.free()
+        block_i0 = api.merge_bwt(d_lbwt, d_rbwt, ls, rs, L["i0"], R["i0"], last_left, bvA, d_bbwt)
+        if not L.get("keep_inputs"):
+            d_lbwt.free(); d_rbwt.free()
         # ---- step 5: pass B, the tail streamed through rank(block BWT) (:500-514)
         rankB = api.rank_build(d_bbwt, bs)
         d_bbwt.free()
         gapB = api.DeviceBuffer(4 * (bs + 2))
         T = n - e
-        _, stB = api.stream_gap(rankB, block_i0, text[e - 1], d_text.at(e), T, gt_cur, 0, gapB, gt_new, max_chains, fresh_gap=True)
-        rankB.free()
+        _, stB = api.stream_gap(rankB, block_i0, last_block_sym, d_text.at(e), T, gt_cur, 0, gapB, gt_new, max_chains, fresh_gap=True,
+                                search=search_for(e, [hbL, hbR]), tail_begin_abs=e)
         if stats is not None:
+            stB.rank_bytes = rankB.device_bytes()
             stats.append(("B", b, e, stB))
+        rankB.free()
         api.bitcopy(gt_new, n - e, gtA, 0, rs)
         api.bitcopy(gt_new, n - mid, d_lgt, 0, ls)
         # ---- step 6: split into the half-block merge bitvectors (:536-542)
@@ -207,8 +244,19 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         hbL["mbv"], hbR["mbv"] = mbvL, mbvR
         half_blocks += [hbL, hbR]
         gt_cur, gt_new = gt_new, gt_cur
+    gt_cur.free(); gt_new.free()
     half_blocks.sort(key=lambda h: h["beg"])       # merge.hpp:59
     half_blocks[-1]["mbv"] = None
+    if timings is not None:
+        api.sync()
+        timings["passes_done"] = _time.perf_counter()
+    if merge == "stream":
+        res = api.merge_stream(half_blocks, slice_entries, sink, check_text=d_text if check_samples is not None else None, n=n,
+                               samples_per_slice=check_samples or 0)
+        for h in half_blocks:
+            if h.get("mbv") is not None:
+                h["mbv"].free()
+        return res
     d_out = api.merge_half_blocks(half_blocks)
     if return_device:
         return d_out
