@@ -434,6 +434,7 @@ def config2(args, ctx, n, block):
             pins.append(pa)
             prepared[(hb, he)] = {"device": True, "psa_host": pa.array, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
                                   "initA": init, "keep_inputs": True}
+    L.psg_trim()        # the sorter's temporaries go back to the driver: the step starts from the resident inputs only
     log(f"prepared {n / 2 ** 30:.2f} GiB {args.text} text, {len(prepared)} half-blocks in {time.time() - t0:.1f}s (device sort {tsort:.1f}s, pinned alloc + D2H {tpin:.1f}s)")
 
     class Replay:

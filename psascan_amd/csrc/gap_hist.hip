@@ -20,9 +20,9 @@
 
 using namespace psg;
 
-#define WBITS 14
+#define WBITS 15           // counters per window: two 16-bit counters share an LDS word (64 KiB per histogram)
 #define WSIZE (1 << WBITS)
-#define CAP (1 << 17)      // log entries per histogram work item
+#define CAP 61440          // log entries per histogram work item: < 2^16, so a 16-bit counter cannot wrap inside one item
 #define PBINS 512          // bins per partition level
 #ifndef PT
 #define PT 16384           // entries per partition tile (runs of ~128 B per bin: full-line writes, tools/membench)
@@ -217,16 +217,25 @@ __device__ __forceinline__ u32 p2_bin(u32 v, int shift, u32 base) {
   return b < PBINS - 1 ? b : PBINS - 1;
 }
 
-// Key sources of a partition pass: entry -> (value to write, bin).
-struct Keys32 {            // a 32-bit rank log: bin = (v >> shift) - base, see p2_bin
-  const u32 *k; int shift; u32 base;
+// Key sources of the level-1 pass: entry -> (bin, value RELATIVE to the start of the bin).  Level 1 writes bin-relative
+// values, so whatever the width of the ranks, everything behind level 1 works on 32-bit values: the window of a
+// value is (bin << bits2) + (value >> WBITS), its counter value & (WSIZE - 1).
+struct Keys32 {            // a 32-bit rank log
+  const u32 *k; int shift; int relative;   // relative = 0: keep the value (level 2: the bin base is handled by p2_bin's base)
+  u32 base;
   template <int EPT> __device__ __forceinline__ void load_tile(u32 (&v)[EPT], u32 (&b)[EPT], i64 beg, i64 end) const {
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) { i64 i = beg + j * P2T + threadIdx.x; v[j] = i < end ? k[i] : PAD; b[j] = p2_bin(v[j], shift, base); }
+    for (int j = 0; j < EPT; ++j) {
+      i64 i = beg + j * P2T + threadIdx.x;
+      const u32 x = i < end ? k[i] : PAD;
+      b[j] = p2_bin(x, shift, base);
+      v[j] = (x == PAD || !relative) ? x : x - (b[j] << shift);
+    }
   }
 };
-struct Keys40 {            // ranks of up to 40 bits in two planes (stream kernel MODE 3): bin = slab of 2^slab_shift counters,
-  const u32 *lo; const u8 *hi; int slab_shift;   // value = rank relative to the slab start.  beg, end multiples of 4.
+struct Keys40 {            // ranks of up to 40 bits in two planes (stream kernel MODE 3), restricted to the counters
+  const u32 *lo; const u8 *hi; int shift;   // [slab_lo, slab_hi) (everything else reads as "no entry"); beg, end multiples of 4
+  u64 slab_lo, slab_hi;
   template <int EPT> __device__ __forceinline__ void load_tile(u32 (&v)[EPT], u32 (&b)[EPT], i64 beg, i64 end) const {
     static_assert(EPT % 4 == 0, "four consecutive entries per thread and load");
 #pragma unroll
@@ -240,9 +249,11 @@ struct Keys40 {            // ranks of up to 40 bits in two planes (stream kerne
       for (int q = 0; q < 4; ++q) {
         const u32 hb = (h >> (8 * q)) & 255u;
         const u64 x = ((u64)hb << 32) | lw[q];
-        const u32 sl = (u32)(x >> slab_shift);
-        b[4 * jj + q] = sl < PBINS - 1 ? sl : PBINS - 1;
-        v[4 * jj + q] = (lw[q] == PAD && hb == 0xFFu) ? PAD : (u32)(x & ((1ull << slab_shift) - 1ull));
+        const bool in = x >= slab_lo && x < slab_hi && !(lw[q] == PAD && hb == 0xFFu);
+        const u64 xr = x - slab_lo;
+        const u64 bin = xr >> shift;
+        b[4 * jj + q] = bin < PBINS - 1 ? (u32)bin : PBINS - 1;
+        v[4 * jj + q] = in ? (u32)(xr - ((u64)b[4 * jj + q] << shift)) : PAD;
       }
     }
   }
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
 #pragma unroll
     for (int j = 0; j < 8; ++j) { i64 k = k0 + j * P2T + threadIdx.x; v[j] = k < se ? keys[k] : PAD; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.cnt[p2_bin(v[j], WBITS, base)], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&S.cnt[p2_bin(v[j], WBITS, 0u)], 1u);   // values are relative to the bin
   }
   __syncthreads();
   u32 tot;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(P2T) void p2_level2_kernel(const u32 *keys, const u
   if (blockIdx.x == PBINS - 1 && threadIdx.x == 0) win_off[nwin] = onext;
   for (u64 k = obase + tot + threadIdx.x; k < onext; k += P2T) out[k] = PAD;
   __syncthreads();
-  const Keys32 K2{keys, WBITS, base};
+  const Keys32 K2{keys, WBITS, 0, 0u};
   if (nsub > P2L2_A) p2_run<P2L2_EA>(S, K2, sb, se, out);
   else if (nsub > P2L2_B) p2_run<P2L2_EB>(S, K2, sb, se, out);
   else p2_run<1>(S, K2, sb, se, out);
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(PSG_WG) void zero_multi_item_windows_kernel(const u
 #define HWG 512
 template <bool OVERWRITE>
 __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, const u64 *n_items, i64 nwin, i64 m, u32 *gap, int *ovf) {
-  __shared__ __attribute__((aligned(16))) u32 h[WSIZE];
+  __shared__ __attribute__((aligned(16))) u32 h[WSIZE / 2];   // counter c = half (c & 1) of word c >> 1; an item adds at most CAP < 2^16 to it
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
   if (item >= (i64)*n_items) return;   // the grid is an upper bound (no host round trip for the item count)
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
     }
     s_w = lo;
   }
-  for (int k = threadIdx.x; k < WSIZE / 4; k += HWG) ((uint4 *)h)[k] = make_uint4(0, 0, 0, 0);
+  for (int k = threadIdx.x; k < WSIZE / 8; k += HWG) ((uint4 *)h)[k] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   i64 w = s_w;
   i64 sub = item - (i64)item_pref[w];
@@ -450,16 +461,17 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { i64 k = k0 + j * HWG + threadIdx.x; v[j] = k < end ? keys[k] : PAD; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[v[j] & (WSIZE - 1)], 1u);
+    for (int j = 0; j < 8; ++j) if (v[j] != PAD) atomicAdd(&h[(v[j] & (WSIZE - 1)) >> 1], 1u << (16 * (v[j] & 1u)));
   }
   __syncthreads();
   i64 base = w << WBITS;
   bool vec = single && base + WSIZE - 1 <= m && ((uintptr_t)(gap + base) & 15) == 0;
-  if (vec) {   // whole window inside the array: coalesced 16-byte read-modify-writes
+  if (vec) {   // whole window inside the array: coalesced 16-byte read-modify-writes, 4 counters (2 LDS words) per access
     for (int k = threadIdx.x; k < WSIZE / 4; k += HWG) {
-      uint4 c = ((const uint4 *)h)[k];
+      const uint2 p = ((const uint2 *)h)[k];
+      const uint4 c = make_uint4(p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16);
       if (OVERWRITE) ((uint4 *)(gap + base))[k] = c;
-      else if (c.x | c.y | c.z | c.w) {
+      else if (p.x | p.y) {
         uint4 *gp = (uint4 *)(gap + base) + k;
         uint4 g = *gp;
         uint4 o = g;
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
     }
   } else {
     for (int k = threadIdx.x; k < WSIZE; k += HWG) {
-      u32 c = h[k];
+      u32 c = (h[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
       i64 idx = base + k;
       if (OVERWRITE && single) { if (idx <= m) gap[idx] = c; }
       else if (c && idx <= m) {
@@ -481,17 +493,21 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
   }
 }
 
-int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
+// KEYS: Keys32 / Keys40 with every field but `shift` filled in
+template <class KEYS>
+static int hist_job_launch(HistJob &J, KEYS K1, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
   static_assert(P2T == PBINS, "p2_level2_kernel maps one sub-bin to one thread");
   J.s = stream();
   J.ev_begin = event_acquire(); J.ev_end = event_acquire();
   (void)hipEventRecord(J.ev_begin, J.s);
-  const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18 for m < 2^32
+  const i64 nwin = ((m + 1) + WSIZE - 1) >> WBITS;   // <= 2^18: up to 2^33 counters per call
   // level 2 only when there are > 512 windows: 511 level-1 bins of 2^bits2 windows + a top bin that takes the
-  // rest (<= 512 windows).  m + 1 = 2^31 + 1 (a 2 GiB half-block) thus uses all 512 bins, not 257 of them.
+  // rest (<= 512 windows).  m + 1 = 2^32 + 1 (a 4 GiB block) thus uses 257 full bins, not 512 half-empty ones.
   int bits2 = 0;
   if (nwin > PBINS) { bits2 = 1; while (nwin - (i64)(PBINS - 1) * ((i64)1 << bits2) > PBINS) ++bits2; }
+  PSG_REQUIRE(bits2 <= 9, "gap histogram: more than 2^33 counters in one call");
   const int shift1 = WBITS + bits2;
+  K1.shift = shift1;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -506,10 +522,9 @@ int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bo
   if ((rc = J.part1.alloc(cap1 * 4)) || (rc = J.counts.alloc((i64)G * PBINS * 4)) || (rc = J.off.alloc((i64)G * PBINS * 8)) ||
       (rc = J.bin_base.alloc((PBINS + 1) * 8)) || (rc = J.win_off.alloc((nwin_slots + 1) * 8)) || (rc = J.cnt.alloc(nwin_slots * 8)) || (rc = J.tot.alloc(8)))
     return rc;
-  const Keys32 K1{d_log, shift1, 0u};
-  hipLaunchKernelGGL(p2_count_kernel<Keys32>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.counts.as<u32>());
+  hipLaunchKernelGGL(p2_count_kernel<KEYS>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.counts.as<u32>());
   hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, J.s, J.counts.as<u32>(), G, J.off.as<u64>(), J.bin_base.as<u64>());
-  hipLaunchKernelGGL(p2_scatter_kernel<Keys32>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.off.as<u64>(), J.part1.as<u32>());
+  hipLaunchKernelGGL(p2_scatter_kernel<KEYS>, dim3(G), dim3(P2T), 0, J.s, K1, nlog, chunk, J.off.as<u64>(), J.part1.as<u32>());
   PSG_HIP(hipGetLastError());
   const u32 *sorted = J.part1.as<u32>();
   const u64 *woff = J.bin_base.as<u64>();
@@ -533,6 +548,10 @@ int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bo
   (void)hipEventRecord(J.ev_end, J.s);
   J.active = true;
   return 0;
+}
+
+int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
+  return hist_job_launch(J, Keys32{d_log, 0, 1, 0u}, nlog, m, d_gap, overwrite);
 }
 
 int psg::gap_hist_wait(HistJob &J, double *ms) {
@@ -560,49 +579,26 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, 
   return gap_hist_wait(job, ms);
 }
 
-// Ranks of up to 40 bits (m >= 2^32 - 1): split the two-plane log into slabs of 2^slab_shift counters with the
-// level-1 machinery (bin = slab, values relative to the slab start, segments padded to whole units), then run the
-// 32-bit histogram on every slab.  PSG_LOG_SLAB_SHIFT makes the slabs small so that tests cross several of them.
+// Ranks of up to 40 bits (m >= 2^32 - 1).  One call of the partition covers 2^33 counters (2^18 windows), so the gap
+// array is cut into slabs of 2^33 counters and the two-plane log is partitioned once per slab, entries of the other
+// slabs reading as "no entry" (one slab for blocks up to 8 Gi symbols; a separate slab-split pass cost 14 ms per 2^31
+// entries, more than a level of the partition itself).  PSG_LOG_SLAB_SHIFT makes the slabs small so that tests
+// cross several of them.
 int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
-  int slab_shift = 31;
-  if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 31) slab_shift = v; }
-  while (((m >> slab_shift) + 1) > PBINS) ++slab_shift;   // at most 512 slabs (only reachable with a test-sized shift)
-  if (slab_shift > 31) { set_error("gap histogram: block too large"); return PSG_EINVAL; }
+  int slab_shift = 33;
+  if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 33) slab_shift = v; }
   const i64 nslab = (m >> slab_shift) + 1;
-  EventTimer tm;
-  tm.start();
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, P2TS)));
-  const i64 chunk = cdiv(cdiv(nlog, G), P2TS) * P2TS;
-  DevBuf slabs, counts, off, bin_base;
-  int rc;
-  const i64 cap = nlog + P2SLACK * G + 64;
-  if ((rc = slabs.alloc(cap * 4)) || (rc = counts.alloc((i64)G * PBINS * 4)) || (rc = off.alloc((i64)G * PBINS * 8)) || (rc = bin_base.alloc((PBINS + 1) * 8))) return rc;
-  const Keys40 K0{log_lo.as<u32>(), log_hi.as<u8>(), slab_shift};
-  hipLaunchKernelGGL(p2_count_kernel<Keys40>, dim3(G), dim3(P2T), 0, stream(), K0, nlog, chunk, counts.as<u32>());
-  hipLaunchKernelGGL(p2_offsets_kernel, dim3(1), dim3(PBINS), 0, stream(), counts.as<u32>(), G, off.as<u64>(), bin_base.as<u64>());
-  hipLaunchKernelGGL(p2_scatter_kernel<Keys40>, dim3(G), dim3(P2T), 0, stream(), K0, nlog, chunk, off.as<u64>(), slabs.as<u32>());
-  PSG_HIP(hipGetLastError());
-  u64 *bb = (u64 *)pinned_buf(4, (PBINS + 1) * 8);
-  if (!bb) { set_error("gap histogram: pinned host allocation failed"); return PSG_ENOMEM; }
-  PSG_HIP(hipMemcpyAsync(bb, bin_base.p, (PBINS + 1) * 8, hipMemcpyDeviceToHost, stream()));
-  tm.stop();
-  PSG_HIP(psg::sync_stream());
-  double total = tm.ms();
-  log_lo.alloc(16); log_hi.alloc(16);   // the planes are dead: their memory serves the per-slab partitions
+  double total = 0;
   for (i64 sl = 0; sl < nslab; ++sl) {
     const i64 base = sl << slab_shift, ms_ = std::min<i64>(((i64)1 << slab_shift) - 1, m - base);   // counters [0, ms_] of this slab
-    const i64 beg = (i64)bb[sl], cnt = (i64)bb[sl + 1] - beg;
-    if (cnt == 0) {
-      if (overwrite) PSG_HIP(hipMemsetAsync(d_gap + base, 0, (size_t)(ms_ + 1) * 4, stream()));
-      continue;
-    }
+    HistJob job;
+    const Keys40 K{log_lo.as<u32>(), log_hi.as<u8>(), 0, (u64)base, (u64)base + (u64)ms_ + 1};
+    if (int rc = hist_job_launch(job, K, nlog, ms_, d_gap + base, overwrite)) return rc;
     double t = 0;
-    if ((rc = gap_hist_from_log(slabs.as<u32>() + beg, cnt, ms_, d_gap + base, &t, overwrite))) return rc;
+    if (int rc = gap_hist_wait(job, &t)) return rc;
     total += t;
   }
+  log_lo.alloc(16); log_hi.alloc(16);
   if (ms) *ms = total;
   return 0;
 }
