@@ -7,6 +7,10 @@
 //                --check[=N]      verify the output on the device while it is merged (permutation sum + N sampled
 //                                 adjacent pairs per slice in suffix order); failure = exit status 1
 //                --discard-output produce the .sa5 bytes (they reach host memory) but write no file
+//                --spill-psa      keep the partial suffix arrays in part files next to GAPFILE (-g; default: the
+//                                 output name) instead of host memory: `GAPFILE.psa.<beg>` is written when a block
+//                                 is done and mapped back for the merge (the reference's distributed_file,
+//                                 io/distributed_file.hpp:58-67); host memory then holds one block at a time
 //
 // Memory tiers: the text, the gt bits and every half-block's merge bitvector stay in HBM; the partial suffix
 // arrays stay in HOST memory where the sorter wrote them (the reference keeps them in part files,
@@ -65,7 +69,9 @@ static void usage(int status) {
          "      --chains=N          cap the number of chains per streaming pass (extension)\n"
          "      --check[=N]         verify the output on the device: permutation sum and N (default\n"
          "                          4096) sampled adjacent pairs per slice in suffix order (extension)\n"
-         "      --discard-output    do everything but write the output file (extension)\n",
+         "      --discard-output    do everything but write the output file (extension)\n"
+         "      --spill-psa         partial suffix arrays in part files GAPFILE.psa.* instead of host\n"
+         "                          memory (extension)\n",
          program_name);
   std::exit(status);
 }
@@ -107,8 +113,49 @@ struct Dev {  // owning device buffer
   template <class T> T *as() const { return (T *)p; }
 };
 
-// a finished half-block: the partial SA stays in host memory, the merge bitvector in HBM
-struct DoneHalfBlock { int64_t beg, size; std::vector<uint32_t> psa_lo; std::vector<uint8_t> psa_hi; Dev mbv; };
+// a finished half-block: the partial SA stays in host memory (or in a part file, --spill-psa), the merge bitvector in HBM
+struct DoneHalfBlock {
+  int64_t beg = 0, size = 0;
+  std::vector<uint32_t> psa_lo;
+  std::vector<uint8_t> psa_hi;
+  Dev mbv;
+  std::string part_file;          // --spill-psa: [size x u32 low words][size x u8 high bytes, if any]
+  bool part_has_hi = false;
+  void *map = nullptr;
+  size_t map_bytes = 0;
+  DoneHalfBlock() {}
+  DoneHalfBlock(const DoneHalfBlock &) = delete;
+  DoneHalfBlock &operator=(const DoneHalfBlock &) = delete;
+  DoneHalfBlock(DoneHalfBlock &&o) noexcept { take(o); }
+  DoneHalfBlock &operator=(DoneHalfBlock &&o) noexcept { if (this != &o) { drop(); take(o); } return *this; }
+  ~DoneHalfBlock() { drop(); }
+  void drop() { if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty()) remove(part_file.c_str()); part_file.clear(); }
+  void take(DoneHalfBlock &o) {
+    beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv);
+    part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
+  }
+  void spill(const std::string &prefix) {
+    part_file = prefix + ".psa." + std::to_string(beg);
+    FILE *f = fopen(part_file.c_str(), "wb");
+    bool ok = f && fwrite(psa_lo.data(), 4, (size_t)size, f) == (size_t)size;
+    part_has_hi = !psa_hi.empty();
+    if (ok && part_has_hi) ok = fwrite(psa_hi.data(), 1, (size_t)size, f) == (size_t)size;
+    if (f) ok = fclose(f) == 0 && ok;
+    if (!ok) throw std::runtime_error("cannot write the part file " + part_file);
+    std::vector<uint32_t>().swap(psa_lo);
+    std::vector<uint8_t>().swap(psa_hi);
+  }
+  void map_back() {
+    if (part_file.empty()) return;
+    int fd = open(part_file.c_str(), O_RDONLY);
+    map_bytes = (size_t)size * (part_has_hi ? 5 : 4);
+    map = fd >= 0 ? mmap(nullptr, map_bytes, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
+    if (fd >= 0) close(fd);
+    if (map == MAP_FAILED) { map = nullptr; throw std::runtime_error("cannot map the part file " + part_file); }
+  }
+  const uint32_t *lo() const { return map ? (const uint32_t *)map : psa_lo.data(); }
+  const uint8_t *hi() const { return map ? (part_has_hi ? (const uint8_t *)map + 4 * (size_t)size : nullptr) : (psa_hi.empty() ? nullptr : psa_hi.data()); }
+};
 
 struct MappedFile {   // read-only view of the input (the page cache is the host copy of the text)
   const uint8_t *p = nullptr;
@@ -143,7 +190,7 @@ static void log_phase(const char *what, double t0, int64_t units = 0) {
   else fprintf(stderr, "    %s: %.2fs\n", what, dt);
 }
 
-struct Options { int64_t forced_block = 0, max_chains = 0, check_samples = -1; bool discard = false; };
+struct Options { int64_t forced_block = 0, max_chains = 0, check_samples = -1; bool discard = false, spill_psa = false; std::string gap_prefix; };
 
 static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt) {
   const int64_t forced_block = opt.forced_block, max_chains = opt.max_chains;
@@ -345,6 +392,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (rs == 0) {
       DoneHalfBlock hbL = keep_hb(L);
       CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      if (opt.spill_psa) hbL.spill(opt.gap_prefix);
       hbs.push_back(std::move(hbL));
       std::swap(gt_cur, gt_new);
       continue;
@@ -376,6 +424,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       hbL.mbv = std::move(bvA);
       CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
       CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
       hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
       std::swap(gt_cur, gt_new);
       continue;
@@ -409,6 +458,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     hbR.mbv.alloc(4 * ((rs + T + 31) / 32 + 2));
     CK(psg_split_gap(gapB.as<uint32_t>(), bvA.as<uint32_t>(), ls, rs, T, hbL.mbv.as<uint32_t>(), hbR.mbv.as<uint32_t>()));
     log_phase("Compute gaps of half-blocks (device)", t0, bs);
+    if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
   }
@@ -420,9 +470,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   double t0 = wclock();
   std::sort(hbs.begin(), hbs.end(), [](const DoneHalfBlock &a, const DoneHalfBlock &b) { return a.beg < b.beg; });
   std::vector<psg_hb_host_desc> desc(hbs.size());
-  for (size_t h = 0; h < hbs.size(); ++h)
-    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].psa_lo.data(), hbs[h].psa_hi.empty() ? nullptr : hbs[h].psa_hi.data(),
-                               h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
+  for (size_t h = 0; h < hbs.size(); ++h) {
+    hbs[h].map_back();
+    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
+  }
   struct SinkCtx { FILE *out; bool ok; int64_t entries; } sctx{out, true, 0};
   psg_sink_fn sink = [](void *c, const uint8_t *h_sa5, int64_t, int64_t cnt) -> int {
     SinkCtx *x = (SinkCtx *)c;
@@ -460,7 +511,8 @@ int main(int argc, char **argv) {
   static struct option long_options[] = {{"help", no_argument, NULL, 'h'}, {"gap", required_argument, NULL, 'g'}, {"mem", required_argument, NULL, 'm'},
                                          {"output", required_argument, NULL, 'o'}, {"verbose", no_argument, NULL, 'v'},
                                          {"block-size", required_argument, NULL, 1000}, {"chains", required_argument, NULL, 1001},
-                                         {"check", optional_argument, NULL, 1002}, {"discard-output", no_argument, NULL, 1003}, {NULL, 0, NULL, 0}};
+                                         {"check", optional_argument, NULL, 1002}, {"discard-output", no_argument, NULL, 1003},
+                                         {"spill-psa", no_argument, NULL, 1004}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
   Options opt;
@@ -479,6 +531,7 @@ int main(int argc, char **argv) {
       case 1001: opt.max_chains = atoll(optarg); break;
       case 1002: opt.check_samples = optarg ? atoll(optarg) : 4096; if (opt.check_samples < 0) opt.check_samples = 0; break;
       case 1003: opt.discard = true; break;
+      case 1004: opt.spill_psa = true; break;
       default: usage(EXIT_FAILURE); break;
     }
   }
@@ -487,6 +540,7 @@ int main(int argc, char **argv) {
   if (optind < argc) fprintf(stderr, "Warning: multiple input files provided. Only the first will be processed.\n");
   if (output_filename.empty()) output_filename = text_filename + ".sa5";
   if (gap_filename.empty()) gap_filename = output_filename;
+  opt.gap_prefix = gap_filename;
   if (!file_exists(text_filename)) { fprintf(stderr, "Error: input file (%s) does not exist\n\n", text_filename.c_str()); usage(EXIT_FAILURE); }
   if (!opt.discard && file_exists(output_filename)) {   // main.cpp:216-238
     char *line = NULL; size_t buflen = 0; ssize_t len = 0;

@@ -283,8 +283,13 @@ def test_cli_check_and_discard(tmp_path):
     r = subprocess.run([CLI, "-m", "1G", "--block-size", str(1 << 20), "--check", "--discard-output", str(f)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert sorted(os.listdir(tmp_path)) == ["y.bin"]
-    # same input through the library path gives the same bytes
     assert len(want) == 64
+    # partial SAs in part files next to GAPFILE (the reference's distributed_file): same bytes, files removed at the end
+    r = subprocess.run([CLI, "-m", "1G", "--block-size", str(1 << 20), "--spill-psa", "-g", str(tmp_path / "tmp_gap"), "-v", str(f)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert hashlib.sha256((tmp_path / "y.bin.sa5").read_bytes()).hexdigest() == want
+    assert sorted(os.listdir(tmp_path)) == ["y.bin", "y.bin.sa5"]
 
 
 @pytest.mark.gpu
