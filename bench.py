@@ -135,7 +135,7 @@ def cpu_baseline(api, extras, sample_mib, log, mode=None):
         for t in range(nthr):
             end_t = min(mid + (t + 1) * S, n)
             if end_t < n:
-                scratch = api.zeros(4 * (mid + 2))
+                scratch = api.gap_array(mid)
                 ir[t], _ = api.stream_gap(rk, Lh["i0"], int(text[mid - 1]), d_text.at(end_t), n - end_t, d_rgt, 0, scratch, None)
                 scratch.free()
         rk.free()
@@ -243,7 +243,7 @@ def config1(args, ctx, gib, steps, warmup, text_mode, with_baselines):
     ob, oe = out_cuts[rank], out_cuts[rank + 1]
     ctx = D.context_len(te, n)           # right context for the start rank of this range
     gt_words = max(cuts[r + 1] - cuts[r] for r in range(world)) // 32 + 4
-    gap_words = ls + 2
+    gap_words = api.gap_words(ls)
     if world > 1:
         a2a_ops = D.HipA2AOps(torch, api, "cuda", full_sync=True)   # device-wide sync around every collective: cheap next to the collectives, and independent of stream identity
         gt_mine = torch.zeros(gt_words, dtype=torch.int32, device="cuda")

@@ -404,7 +404,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     psg_rank_t *rankL = nullptr;
     CK(psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL));
     log_phase("Construct rank (left half, device)", t0, ls);
-    Dev gapA(4 * (ls + 2), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
+    Dev gapA(4 * psg_gap_words(ls), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
     int64_t initA = psa_host::rank_by_search(text.data(), n, L, e);
     const int64_t L_i0 = L.i0, R_i0 = R.i0;
     DoneHalfBlock hbL = keep_hb(L), hbR = keep_hb(R);
@@ -443,7 +443,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     d_bbwt.release();
     log_phase("Construct rank (block, device)", t0, bs);
     const int64_t T = n - e;
-    Dev gapB(4 * (bs + 2), false);
+    Dev gapB(4 * psg_gap_words(bs), false);
     t0 = wclock();
     stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(), gt_new.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi}}, &st);

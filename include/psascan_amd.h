@@ -36,7 +36,7 @@ extern "C" {
 #define PSG_EINVAL (-1)   /* bad argument                                  */
 #define PSG_EDEVICE (-2)  /* HIP runtime error / no device                 */
 #define PSG_ENOMEM (-3)   /* device allocation failed                      */
-#define PSG_EOVERFLOW (-4)/* a u32 gap counter would overflow              */
+#define PSG_EOVERFLOW (-4)/* (unused since the gap arrays carry an excess list) */
 #define PSG_ECHECK (-5)   /* an internal invariant check failed            */
 
 /* ---- runtime ------------------------------------------------------------------------ */
@@ -61,6 +61,22 @@ int psg_set_stream(void *hip_stream);
 
 /* ---- rank over a block BWT: replaces `new rank4n<>(bwt, m, threads)`,
  *      partial_sufsort.hpp:403,500 ; semantics rank.hpp:566-568, m_count rank.hpp:112 --- */
+/* ---- gap arrays: buffered_gap_array (gap_array.hpp:55-383).  A gap array over m+1 slots is psg_gap_words(m)
+ *      uint32 words: words [0, m] are the counters; behind them (16-byte aligned) an EXCESS LIST: a slot whose
+ *      counter wraps gets an entry appended by an atomic cursor and keeps counting from 0, exactly as the
+ *      reference's u8 counters do with their excess list (update.hpp:88-96, gap_array.hpp:79-88):
+ *          value(j) = counter[j] + 2^32 * #{entries equal to j}           (gap_array.hpp:116-124)
+ *      Every consumer (psg_gap_to_bitvector, psg_split_gap, psg_gap_values, ...) works on value(j).  An all-zero
+ *      array is a valid empty gap array; PSG_GAP_UNINITIALIZED passes initialise it themselves.  n <= 2^40 bounds
+ *      the list at 256 entries; it has room for PSG_GAP_EXCESS_CAP.  (Tests shrink the counters to 8 or 16 bits
+ *      with PSG_GAP_COUNTER_BITS so that the excess path runs at small sizes.)                                  */
+#define PSG_GAP_EXCESS_CAP 65536
+#define PSG_GAP_HDR_WORD(m) ((((int64_t)(m) + 1) + 3) & ~(int64_t)3)
+#define PSG_GAP_WORDS(m) (PSG_GAP_HDR_WORD(m) + 4 + 2 * (int64_t)PSG_GAP_EXCESS_CAP)
+int64_t psg_gap_words(int64_t m);
+/* d_out[j] = value(j) for j in [0, m] (counters + excess), as 64-bit values */
+int psg_gap_values(const uint32_t *d_gap, int64_t m, uint64_t *d_out);
+
 typedef struct psg_rank psg_rank_t;
 /* data_bytes_per_block: 0 = choose from the alphabet (64, or 48 when sigma <= 4).        */
 int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes_per_block, psg_rank_t **out);
@@ -77,7 +93,7 @@ void psg_rank_free(psg_rank_t *r);
  *                   rank was built on; bit u <-> position tail_end - u; NULL = all zero
  *  rank_at_tail_end number of block suffixes smaller than text[tail_end..n)
  *                   (the reference's initial_ranks.back(), stream.hpp:66,108)
- *  d_gap            m+1 uint32 counters, INCREMENTED (zero them first for a fresh array);
+ *  d_gap            gap array of psg_gap_words(m) words, INCREMENTED (zero all of it first for a fresh array);
  *                   value semantics of buffered_gap_array (gap_array.hpp:116-124)
  *  d_gt_out         tail_len bits written: bit u = [text[tail_end-u..n) > text[block_beg..n)]
  *                   (stream.hpp:150); may be NULL

@@ -71,6 +71,8 @@ SIGNATURES = {
     "psg_host_free": (_int, [_vp]),
     "psg_mem_stats": (_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "psg_set_stream": (_int, [_vp]),
+    "psg_gap_words": (_i64, [_i64]),
+    "psg_gap_values": (_int, [_vp, _i64, _vp]),
     "psg_rank_build": (_int, [_vp, _i64, _int, C.POINTER(_vp)]),
     "psg_rank_counts": (_int, [_vp, C.POINTER(_i64)]),
     "psg_rank_device_bytes": (_i64, [_vp]),

@@ -166,6 +166,49 @@ def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, ran
     return fin.value, StreamStats(st)
 
 
+def gap_words(m):
+    """uint32 words of a gap array over m + 1 slots (counters + in-band excess list, psg_gap_words)"""
+    return ((m + 1 + 3) & ~3) + 4 + 2 * 65536
+
+
+def gap_array(m, fill=0):
+    """A gap array over m + 1 slots.  fill=0: empty (all zero); fill=None: uninitialised (for PSG_GAP_UNINITIALIZED
+    passes); another value: every counter starts at it (tests of accumulating passes)."""
+    if fill is None:
+        return DeviceBuffer(4 * gap_words(m))
+    b = zeros(4 * gap_words(m))
+    if fill:
+        a = np.full(m + 1, fill, np.uint32)
+        check(lib().psg_h2d(b.ptr, a.ctypes.data, a.nbytes))
+    return b
+
+
+def gap_array_from_values(values, bits=32):
+    """A gap array holding the given 64-bit values: counters = low `bits` bits, one excess entry per 2^bits above."""
+    v = np.ascontiguousarray(values, np.uint64)
+    m = len(v) - 1
+    b = zeros(4 * gap_words(m))
+    cells = (v & np.uint64((1 << bits) - 1)).astype(np.uint32)
+    check(lib().psg_h2d(b.ptr, cells.ctypes.data, cells.nbytes))
+    carries = (v >> np.uint64(bits)).astype(np.int64)
+    ent = np.repeat(np.arange(m + 1, dtype=np.uint64), carries)
+    assert len(ent) <= 65536
+    hdr = np.array([len(ent), bits, 0, 0], np.uint32)
+    hw = ((m + 1 + 3) & ~3)
+    check(lib().psg_h2d(b.ptr + 4 * hw, hdr.ctypes.data, 16))
+    if len(ent):
+        ent = np.ascontiguousarray(ent[np.random.default_rng(1).permutation(len(ent))])     # the list is unordered
+        check(lib().psg_h2d(b.ptr + 4 * hw + 16, ent.ctypes.data, ent.nbytes))
+    return b
+
+
+def gap_values(d_gap, m):
+    """value(j) = counter[j] + 2^bits * #{excess entries equal to j}, as np.uint64[m + 1]"""
+    out = DeviceBuffer(8 * (m + 1))
+    check(lib().psg_gap_values(_ptr(d_gap), m, out.ptr))
+    return download(out, np.uint64, m + 1)
+
+
 def gap_to_bitvector(d_gap, m, d_bv, capacity_bits):
     nbits = C.c_int64(0)
     check(lib().psg_gap_to_bitvector(_ptr(d_gap), m, _ptr(d_bv), capacity_bits, C.byref(nbits)))

@@ -32,17 +32,22 @@ __device__ __forceinline__ void load8_u32(const u32 *v, i64 base, i64 n, u32 (&g
   }
 }
 
-__global__ __launch_bounds__(PSG_WG) void tile_sum_u32_kernel(const u32 *v, i64 n, u64 *tile_sum) {
+// the 8 gap VALUES of slots slot0 + base + q (counters v[base + q] + their excess entries); 0 beyond n
+__device__ __forceinline__ void load8_gap(const u32 *v, i64 base, i64 n, const ExcessView &X, i64 slot0, u64 (&g)[8]) {
+  u32 c[8];
+  load8_u32(v, base, n, c);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) g[q] = c[q];
+  excess_apply8(X, slot0 + base, g);
+}
+
+__global__ __launch_bounds__(PSG_WG) void tile_sum_u32_kernel(const u32 *v, i64 n, u64 *tile_sum, ExcessView X, i64 slot0) {
   __shared__ u64 scratch[8];
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
-  u64 s = 0;
-  if (base + 8 <= n && ((uintptr_t)v & 15) == 0) {   // whole group: two 16-byte loads
-    uint4 a = *(const uint4 *)(v + base), b = *(const uint4 *)(v + base + 4);
-    s = (u64)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-  } else {
+  u64 g[8], s = 0;
+  load8_gap(v, base, n, X, slot0, g);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) if (base + q < n) s += v[base + q];
-  }
+  for (int q = 0; q < 8; ++q) s += g[q];
   u64 tot = block_sum<u64>(s, scratch);
   if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
 }
@@ -111,26 +116,22 @@ __device__ __forceinline__ void bw_flush(BitWindow &W, u32 *bv) {
   }
 }
 
-__global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap, i64 m, const u64 *tile_pref, u32 *bv) {
+__global__ __launch_bounds__(PSG_WG) void gap_to_bv_apply_kernel(const u32 *gap, i64 m, const u64 *tile_pref, u32 *bv, ExcessView X) {
   __shared__ u64 scratch[8];
   __shared__ BitWindow W;
+  __shared__ u64 first_gap;
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
-  u32 g[8];
+  u64 g[8];
   u64 s = 0;
-  if (base + 8 <= m + 1 && ((uintptr_t)gap & 15) == 0) {
-    uint4 a = *(const uint4 *)(gap + base), b = *(const uint4 *)(gap + base + 4);
-    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+  load8_gap(gap, base, m + 1, X, 0, g);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += g[q];
-  } else {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { g[q] = base + q <= m ? gap[base + q] : 0; s += g[q]; }
-  }
+  for (int q = 0; q < 8; ++q) s += g[q];
+  if (threadIdx.x == 0) first_gap = g[0];
   u64 tot;
   u64 tp = tile_pref[blockIdx.x];
-  u64 pre = tp + block_excl_scan<u64>(s, scratch, tot);
+  u64 pre = tp + block_excl_scan<u64>(s, scratch, tot);   // (contains barriers: first_gap is visible)
   // first zero position of the tile: element j0 = blockIdx*TILE_V sits at j0 + tp + gap[j0]
-  bw_init(W, (i64)blockIdx.x * TILE_V + (i64)tp + (i64)gap[(i64)blockIdx.x * TILE_V]);
+  bw_init(W, (i64)blockIdx.x * TILE_V + (i64)tp + (i64)first_gap);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -154,7 +155,10 @@ extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *
   int rc;
   if ((rc = ts.alloc(ntiles * 8)) || (rc = tot.alloc(8))) return rc;
   double w1 = now();
-  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, n, ts.as<u64>());
+  ExcessView X;
+  struct Owned { void *p = nullptr; ~Owned() { if (p) psg::pool_free(p); } } owned;
+  if ((rc = gap_excess_view(d_gap, m, &X, &owned.p))) return rc;
+  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, n, ts.as<u64>(), X, (i64)0);
   PSG_HIP(hipGetLastError());
   double x1 = now();
   if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, tot.as<u64>()))) return rc;
@@ -170,7 +174,7 @@ extern "C" int psg_gap_to_bitvector(const uint32_t *d_gap, int64_t m, uint32_t *
   if (*nbits > cap_bits) { set_error("psg_gap_to_bitvector: output capacity too small"); return PSG_EINVAL; }
   if ((rc = fill_ones(d_bv, *nbits))) return rc;
   double w3 = now();
-  hipLaunchKernelGGL(gap_to_bv_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, m, ts.as<u64>(), d_bv);
+  hipLaunchKernelGGL(gap_to_bv_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, m, ts.as<u64>(), d_bv, X);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());
@@ -222,7 +226,7 @@ extern "C" int psg_gap_slice_to_bits(const uint32_t *d_gap_slice, int64_t j0, in
   DevBuf ts;
   int rc;
   if ((rc = ts.alloc(ntiles * 8))) return rc;
-  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, count, ts.as<u64>());
+  hipLaunchKernelGGL(tile_sum_u32_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, count, ts.as<u64>(), ExcessView{nullptr, 0, 32}, (i64)0);
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(ts.as<u64>(), ntiles, nullptr))) return rc;
   hipLaunchKernelGGL(gap_slice_bits_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap_slice, j0, count, m, (u64)ps_before,
@@ -335,12 +339,12 @@ extern "C" int psg_merge_bwt(const uint8_t *d_l, const uint8_t *d_r, int64_t ml,
 // (closed form of the segment sums of compute_left_gap.hpp:55-123 /
 //  compute_right_gap.hpp:55-122)
 // =======================================================================================
-__global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, const u32 *bv, i64 block, u64 *tile_g, u64 *tile_o) {
+__global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, const u32 *bv, i64 block, u64 *tile_g, u64 *tile_o, ExcessView X) {
   __shared__ u64 scratch[8];
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
   u64 s = 0;
-  u32 g[8];
-  load8_u32(gap, base, block + 1, g);
+  u64 g[8];
+  load8_gap(gap, base, block + 1, X, 0, g);
 #pragma unroll
   for (int q = 0; q < 8; ++q) s += g[q];
   int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
@@ -351,13 +355,13 @@ __global__ __launch_bounds__(PSG_WG) void split_reduce_kernel(const u32 *gap, co
 }
 
 __global__ __launch_bounds__(PSG_WG) void split_apply_kernel(const u32 *gap, const u32 *bv, i64 block, const u64 *tile_g,
-                                                               const u64 *tile_o, u32 *mbv_left, u32 *mbv_right) {
+                                                               const u64 *tile_o, u32 *mbv_left, u32 *mbv_right, ExcessView X) {
   __shared__ u64 scratch[8];
   __shared__ BitWindow WL, WR;
   i64 base = (i64)blockIdx.x * TILE_V + (i64)threadIdx.x * 8;
-  u32 g[8];
+  u64 g[8];
   u64 s = 0;
-  load8_u32(gap, base, block + 1, g);
+  load8_gap(gap, base, block + 1, X, 0, g);
 #pragma unroll
   for (int q = 0; q < 8; ++q) s += g[q];
   int n = (int)std::max<i64>(0, std::min<i64>(8, block - base));
@@ -390,7 +394,10 @@ extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_
   DevBuf tg, to, tot;
   int rc;
   if ((rc = tg.alloc(ntiles * 8)) || (rc = to.alloc(ntiles * 8)) || (rc = tot.alloc(16))) return rc;
-  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, d_bv, block, tg.as<u64>(), to.as<u64>());
+  ExcessView X;
+  struct Owned { void *p = nullptr; ~Owned() { if (p) psg::pool_free(p); } } owned;
+  if ((rc = gap_excess_view(d_gap, block, &X, &owned.p))) return rc;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, d_bv, block, tg.as<u64>(), to.as<u64>(), X);
   PSG_HIP(hipGetLastError());
   if ((rc = scan_u64_inplace(tg.as<u64>(), ntiles, tot.as<u64>()))) return rc;
   if ((rc = scan_u64_inplace(to.as<u64>(), ntiles, tot.as<u64>() + 1))) return rc;
@@ -401,7 +408,7 @@ extern "C" int psg_split_gap(const uint32_t *d_gap, const uint32_t *d_bv, int64_
   if ((i64)t[1] != mr) { set_error("psg_split_gap: bitvector ones=" + std::to_string(t[1]) + " != right size " + std::to_string(mr)); return PSG_ECHECK; }
   if ((rc = fill_ones(d_mbv_left, block + tail_len)) || (rc = fill_ones(d_mbv_right, mr + tail_len))) return rc;
   hipLaunchKernelGGL(split_apply_kernel, dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_gap, d_bv, block, tg.as<u64>(), to.as<u64>(),
-                     d_mbv_left, d_mbv_right);
+                     d_mbv_left, d_mbv_right, X);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());

@@ -96,15 +96,33 @@ struct EventTimer {
 
 static inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
 
+// ---- gap arrays with an in-band excess list (include/psascan_amd.h) ------------------------------------------
+// header words behind the counters: [0] number of entries, [1] counter bits (0 = 32), [2] capacity-exceeded flag,
+// [3] capacity of the list (0 = PSG_GAP_EXCESS_CAP)
+struct GapExcess {          // what a kernel needs to append
+  u32 *hdr;                 // null: no excess handling wanted
+  u64 *ent;
+  int bits;                 // counter width (32 in production; 8/16 in tests)
+};
+static inline u32 *gap_hdr(u32 *gap, i64 m) { return gap + PSG_GAP_HDR_WORD(m); }
+static inline GapExcess gap_excess(u32 *gap, i64 m, int bits) { return GapExcess{gap_hdr(gap, m), (u64 *)(gap_hdr(gap, m) + 4), bits}; }
+// counter width of a gap array as recorded in its header (host round trip); initialises the header of a fresh or
+// all-zero array (PSG_GAP_COUNTER_BITS = 8 | 16: tests).  fresh: the header holds garbage.
+int gap_prepare(u32 *d_gap, i64 m, bool fresh, int *bits);
+// the excess entries sorted by slot, for consumers: *d_sorted is a pool buffer the caller releases (null when n == 0)
+struct ExcessView { const u64 *sorted; u32 n; int bits; };
+int gap_excess_view(const u32 *d_gap, i64 m, ExcessView *view, void **owned);
+
 // gap[v] += #{entries of log equal to v} for v in [0, m]; entries 0xFFFFFFFF are skipped.
 // Sorts the log by its high bits (in place semantics: log is clobbered) and histograms
 // LDS-sized windows -- replaces one random atomic per streamed suffix (gap_hist.hip).
 // overwrite: d_gap holds garbage on entry and exactly the histogram on return (no zero-fill needed)
-int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
+// excess: where counters that wrap leave their carries (slot numbers are offset by slot_base)
+int gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite, GapExcess ex = GapExcess{nullptr, nullptr, 32}, i64 slot_base = 0);
 // the same for ranks of up to 40 bits (blocks of >= 2^32 - 1 symbols): log_lo holds the low words, log_hi one byte per
 // entry with bits 32..39 (no entry = 0xFFFFFFFF / 0xFF).  The log is first split into slabs of 2^31 counters (values
 // relative to the slab start), each slab is then histogrammed like a 32-bit log.  Both buffers are released.
-int gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite);
+int gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite, GapExcess ex);
 // the same in two halves: launch enqueues everything on stream() without waiting for the device, wait
 // blocks until the job is done, checks the overflow flag and releases the job's buffers
 struct HistJob {
@@ -112,8 +130,9 @@ struct HistJob {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipStream_t s = nullptr;
   bool active = false;
+  bool own_excess = false;   // the job's own stand-in excess area: a carry is an error
 };
-int gap_hist_launch(HistJob &job, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite);
+int gap_hist_launch(HistJob &job, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex = GapExcess{nullptr, nullptr, 32}, i64 slot_base = 0);
 int gap_hist_wait(HistJob &job, double *ms);
 
 // property check of `count` packed uint40 entries (prep.hip): acc[0] += sum of the entries (mod 2^64),
@@ -189,4 +208,38 @@ __device__ __forceinline__ u32 get_bits(const u32 *bv, i64 pos, int cnt, i64 nwo
   u64 hi = (sh + cnt > 32 && w + 1 < nwords) ? gload(bv + w + 1) : 0;
   u64 x = (lo | (hi << 32)) >> sh;
   return cnt >= 32 ? (u32)x : (u32)x & ((1u << cnt) - 1u);
+}
+
+// ---- excess list, device side ---------------------------------------------------------------------------------
+// `carries` carries out of slot j: append that many entries (each stands for 2^bits)
+__device__ __forceinline__ void excess_append(const psg::GapExcess &X, u64 j, u32 carries) {
+  if (!carries) return;
+  const u32 pos = atomicAdd(X.hdr, carries);
+  const u32 cap = X.hdr[3] ? X.hdr[3] : (u32)PSG_GAP_EXCESS_CAP;
+  for (u32 t = 0; t < carries; ++t) {
+    if (pos + t < cap) X.ent[pos + t] = j;
+    else X.hdr[2] = 1u;       // cannot happen with 32-bit counters (n <= 2^40 gives at most 256 carries)
+  }
+}
+// counter += c (not atomic: the caller owns the slot); returns the new counter value, appends the carries
+__device__ __forceinline__ u32 excess_add_owned(const psg::GapExcess &X, u64 j, u32 old, u32 c) {
+  const u64 sum = (u64)old + c;
+  if (X.bits >= 32) { if (sum >> 32) excess_append(X, j, 1u); return (u32)sum; }
+  excess_append(X, j, (u32)(sum >> X.bits));
+  return (u32)(sum & ((1ull << X.bits) - 1ull));
+}
+// counter += c with an atomic (other threads add to the same slot): every multiple of 2^bits the running value
+// crosses is turned into one entry; with narrow counters the crossing thread also takes 2^bits off again
+__device__ __forceinline__ void excess_add_atomic(const psg::GapExcess &X, u32 *cell, u64 j, u32 c) {
+  const u32 old = atomicAdd(cell, c);
+  if (X.bits >= 32) { if ((u32)(old + c) < old) excess_append(X, j, 1u); return; }
+  const u32 carries = (u32)((((u64)old + c) >> X.bits) - ((u64)old >> X.bits));
+  if (carries) { atomicSub(cell, carries << X.bits); excess_append(X, j, carries); }
+}
+// values of the slots [base, base + 8): g[q] += 2^bits for every entry equal to base + q
+__device__ __forceinline__ void excess_apply8(const psg::ExcessView &X, i64 base, u64 (&g)[8]) {
+  if (!X.n) return;
+  u32 lo = 0, hi = X.n;
+  while (lo < hi) { const u32 md = (lo + hi) >> 1; if (X.sorted[md] < (u64)base) lo = md + 1; else hi = md; }
+  for (; lo < X.n && X.sorted[lo] < (u64)base + 8; ++lo) g[X.sorted[lo] - (u64)base] += 1ull << X.bits;
 }

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(PSG_WG) void zero_multi_item_windows_kernel(const u
 // 512 threads: the 64 KiB histogram allows two workgroups per CU, and the kernel needs loads in flight
 #define HWG 512
 template <bool OVERWRITE>
-__global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, const u64 *n_items, i64 nwin, i64 m, u32 *gap, int *ovf) {
+__global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const u64 *off, const u64 *item_pref, const u64 *n_items, i64 nwin, i64 m, u32 *gap,
+                                                           GapExcess ex, i64 slot_base) {
   __shared__ __attribute__((aligned(16))) u32 h[WSIZE / 2];   // counter c = half (c & 1) of word c >> 1; an item adds at most CAP < 2^16 to it
   __shared__ i64 s_w;
   i64 item = blockIdx.x;
@@ -470,13 +471,16 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
     for (int k = threadIdx.x; k < WSIZE / 4; k += HWG) {
       const uint2 p = ((const uint2 *)h)[k];
       const uint4 c = make_uint4(p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16);
-      if (OVERWRITE) ((uint4 *)(gap + base))[k] = c;
-      else if (p.x | p.y) {
+      const u64 j0 = (u64)(slot_base + base) + 4 * (u64)k;
+      if (OVERWRITE && ex.bits >= 32) ((uint4 *)(gap + base))[k] = c;
+      else if (OVERWRITE) {     // narrow counters (tests): a window count may already exceed the counter
+        ((uint4 *)(gap + base))[k] = make_uint4(excess_add_owned(ex, j0, 0u, c.x), excess_add_owned(ex, j0 + 1, 0u, c.y),
+                                                excess_add_owned(ex, j0 + 2, 0u, c.z), excess_add_owned(ex, j0 + 3, 0u, c.w));
+      } else if (p.x | p.y) {
         uint4 *gp = (uint4 *)(gap + base) + k;
         uint4 g = *gp;
-        uint4 o = g;
-        g.x += c.x; g.y += c.y; g.z += c.z; g.w += c.w;
-        if (g.x < o.x || g.y < o.y || g.z < o.z || g.w < o.w) *ovf = 1;   // a u32 gap counter wrapped
+        g.x = excess_add_owned(ex, j0, g.x, c.x); g.y = excess_add_owned(ex, j0 + 1, g.y, c.y);
+        g.z = excess_add_owned(ex, j0 + 2, g.z, c.z); g.w = excess_add_owned(ex, j0 + 3, g.w, c.w);   // a wrapping counter leaves a carry in the excess list
         *gp = g;
       }
     }
@@ -484,10 +488,10 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
     for (int k = threadIdx.x; k < WSIZE; k += HWG) {
       u32 c = (h[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
       i64 idx = base + k;
-      if (OVERWRITE && single) { if (idx <= m) gap[idx] = c; }
+      if (OVERWRITE && single) { if (idx <= m) gap[idx] = excess_add_owned(ex, (u64)(slot_base + idx), 0u, c); }
       else if (c && idx <= m) {
-        if (single) { u32 o = gap[idx]; gap[idx] = o + c; if (o + c < o) *ovf = 1; }
-        else if (atomicAdd(&gap[idx], c) + c < c) *ovf = 1;
+        if (single) gap[idx] = excess_add_owned(ex, (u64)(slot_base + idx), gap[idx], c);
+        else excess_add_atomic(ex, &gap[idx], (u64)(slot_base + idx), c);
       }
     }
   }
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(HWG) void hist_items_kernel(const u32 *keys, const 
 
 // KEYS: Keys32 / Keys40 with every field but `shift` filled in
 template <class KEYS>
-static int hist_job_launch(HistJob &J, KEYS K1, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
+static int hist_job_launch(HistJob &J, KEYS K1, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex, i64 slot_base) {
   static_assert(P2T == PBINS, "p2_level2_kernel maps one sub-bin to one thread");
   J.s = stream();
   J.ev_begin = event_acquire(); J.ev_end = event_acquire();
@@ -514,8 +518,11 @@ static int hist_job_launch(HistJob &J, KEYS K1, i64 nlog, i64 m, u32 *d_gap, boo
   const int G = (int)std::min<i64>((i64)cus * 2, std::max<i64>(1, cdiv(nlog, P2TS)));
   const i64 chunk = cdiv(cdiv(nlog, G), P2TS) * P2TS;
   int rc;
-  if ((rc = J.ovf.alloc(4))) return rc;
-  PSG_HIP(hipMemsetAsync(J.ovf.p, 0, 4, J.s));
+  if ((rc = J.ovf.alloc(16 + 64))) return rc;       // stand-in excess area for callers without one (carries flag an error)
+  PSG_HIP(hipMemsetAsync(J.ovf.p, 0, 16 + 64, J.s));
+  PSG_HIP(hipMemsetAsync(J.ovf.as<u32>() + 3, 8, 1, J.s));   // header word 3 = capacity of the list behind it: 8 entries
+  J.own_excess = ex.hdr == nullptr;
+  if (J.own_excess) ex = GapExcess{J.ovf.as<u32>(), (u64 *)(J.ovf.as<u32>() + 4), 32};
   const i64 nwin_slots = (bits2 ? ((i64)PBINS << bits2) : PBINS) + PBINS + 2;
   const i64 cap1 = nlog + P2SLACK * G + 64;                 // level-1 output incl. the rounding of every (workgroup, bin) segment
   const i64 cap2 = cap1 + P2SLACK * (PBINS + 1);
@@ -542,16 +549,16 @@ static int hist_job_launch(HistJob &J, KEYS K1, i64 nlog, i64 m, u32 *d_gap, boo
   // work items: one per window (overwrite) or per non-empty window, plus one per CAP entries; upper bound, the
   // kernel reads the exact count on the device
   const i64 items_max = nwin + (bits2 ? cap2 : cap1) / CAP + 1;
-  if (overwrite) hipLaunchKernelGGL(hist_items_kernel<true>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, J.ovf.as<int>());
-  else hipLaunchKernelGGL(hist_items_kernel<false>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, J.ovf.as<int>());
+  if (overwrite) hipLaunchKernelGGL(hist_items_kernel<true>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, ex, slot_base);
+  else hipLaunchKernelGGL(hist_items_kernel<false>, dim3((unsigned)items_max), dim3(HWG), 0, J.s, sorted, woff, J.cnt.as<u64>(), J.tot.as<u64>(), nwin, m, d_gap, ex, slot_base);
   PSG_HIP(hipGetLastError());
   (void)hipEventRecord(J.ev_end, J.s);
   J.active = true;
   return 0;
 }
 
-int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite) {
-  return hist_job_launch(J, Keys32{d_log, 0, 1, 0u}, nlog, m, d_gap, overwrite);
+int psg::gap_hist_launch(HistJob &J, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex, i64 slot_base) {
+  return hist_job_launch(J, Keys32{d_log, 0, 1, 0u}, nlog, m, d_gap, overwrite, ex, slot_base);
 }
 
 int psg::gap_hist_wait(HistJob &J, double *ms) {
@@ -569,13 +576,13 @@ int psg::gap_hist_wait(HistJob &J, double *ms) {
   J.ev_begin = J.ev_end = nullptr;
   J.part1.alloc(16); J.part2.alloc(16);     // give the big buffers back to the pool
   if (rc) return rc;
-  if (h_ovf) { set_error("gap histogram: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
+  if (h_ovf && J.own_excess) { set_error("gap histogram: a counter wrapped and the caller gave no excess list"); return PSG_ECHECK; }
   return 0;
 }
 
-int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
+int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite, GapExcess ex, i64 slot_base) {
   HistJob job;
-  if (int rc = gap_hist_launch(job, d_log, nlog, m, d_gap, overwrite)) return rc;
+  if (int rc = gap_hist_launch(job, d_log, nlog, m, d_gap, overwrite, ex, slot_base)) return rc;
   return gap_hist_wait(job, ms);
 }
 
@@ -584,7 +591,7 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, 
 // slabs reading as "no entry" (one slab for blocks up to 8 Gi symbols; a separate slab-split pass cost 14 ms per 2^31
 // entries, more than a level of the partition itself).  PSG_LOG_SLAB_SHIFT makes the slabs small so that tests
 // cross several of them.
-int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite) {
+int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite, GapExcess ex) {
   int slab_shift = 33;
   if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 33) slab_shift = v; }
   const i64 nslab = (m >> slab_shift) + 1;
@@ -593,7 +600,7 @@ int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m,
     const i64 base = sl << slab_shift, ms_ = std::min<i64>(((i64)1 << slab_shift) - 1, m - base);   // counters [0, ms_] of this slab
     HistJob job;
     const Keys40 K{log_lo.as<u32>(), log_hi.as<u8>(), 0, (u64)base, (u64)base + (u64)ms_ + 1};
-    if (int rc = hist_job_launch(job, K, nlog, ms_, d_gap + base, overwrite)) return rc;
+    if (int rc = hist_job_launch(job, K, nlog, ms_, d_gap + base, overwrite, ex, base)) return rc;
     double t = 0;
     if (int rc = gap_hist_wait(job, &t)) return rc;
     total += t;

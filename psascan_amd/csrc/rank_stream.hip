@@ -398,9 +398,11 @@ struct StreamParams {
   u32 *log;           // MODE 2/3: rank log (low 32 bits), entry ((step >> 2) * K + chain) * 4 + (step & 3)
   i64 K;              // total number of chains (log row length)
   u32 *log_hi;        // MODE 3: bits 32..39 of the ranks, one byte per entry at the same index (0xFF + low word PAD = no entry)
+  psg::GapExcess ex;  // MODE 1: where wrapping counters leave their carries
 };
 
-// MODE 0: atomicAdd on the gap counters; 1: same with u32 overflow detection;
+// MODE 0: atomicAdd on the gap counters (a fresh array of 32-bit counters and a tail below 2^32: nothing can wrap);
+// MODE 1: the same with carries into the excess list (update.hpp:88-96);
 // MODE 2: no atomics -- the ranks are logged (coalesced dwordx4 stores) and histogrammed afterwards
 //         (gap_hist.hip).
 // MODE 3: MODE 2 for blocks of >= 2^32 - 1 symbols: a second plane takes bits 32..39 of every rank (one dword
@@ -447,7 +449,6 @@ __device__ __forceinline__ TextBlock load_text_block(const uint4 *bp, int first)
 
 template <int CNT, int B, int MODE, int CPL>
 __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
-  constexpr bool CHECK_OVF = MODE == 1;
   extern __shared__ u64 lds[];
   __shared__ u32 lstage[MODE >= 2 ? CPL * 4 * PSG_WG : 1];
   __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
@@ -485,7 +486,6 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
       c.gin = P.gt_in ? P.gt_in[c.w] : 0u;
     }
   }
-  bool ovf = false;
   for (i64 g = 0; g < P.L; g += 32) {
     int steps[CPL], smax = 0;
 #pragma unroll
@@ -533,9 +533,8 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
               ((uint4 *)P.log)[((g + t) >> 2) * P.K + c.k] = q4;
               if (MODE == 3) { P.log_hi[((g + t) >> 2) * P.K + c.k] = c.hiacc; c.hiacc = 0; }
             }
-          } else if (CHECK_OVF) {
-            u32 old = atomicAdd(&P.gap[ni], 1u);
-            ovf |= (old == 0xFFFFFFFFu);
+          } else if (MODE == 1) {
+            excess_add_atomic(P.ex, &P.gap[ni], (u64)ni, 1u);
           } else {
             atomicAdd(&P.gap[ni], 1u);
           }
@@ -599,7 +598,6 @@ __global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void 
       }
     P.fin[c.k] = c.i;
   }
-  if (CHECK_OVF && ovf) *P.ovf_flag = 1;
 }
 
 // Warm-up: find the start rank of chain k by running the recurrence on an interval
@@ -1068,7 +1066,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
               "psg_stream_gap: rank_at_tail_end out of range (-1 = unknown is only allowed with a right context)");
   psg_stream_stats st = {};
   if (T == 0) {
-    if (fresh && d_gap) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));
+    if (fresh && d_gap) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)PSG_GAP_WORDS(r->m) * 4, stream()));
     if (h_final_rank) *h_final_rank = rank_at_end; if (stats) *stats = st; return 0;
   }
   PSG_REQUIRE(d_tail, "psg_stream_gap: tail text required");
@@ -1079,15 +1077,22 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
   for (int c = 0; c < 256; ++c) { i64 t = r->count[c] + (c == last_sym) - (c == 0); C[c] = s; s += t; }
   DevBuf T1, tot;
   if (int rc = make_tables(r, C, T1, tot)) return rc;
+  // the array's counter width / excess list (32 bits unless a test narrows it)
+  int gbits = 32;
+  GapExcess gex{nullptr, nullptr, 32};
+  if (d_gap) {
+    if (int rc = gap_prepare(d_gap, r->m, fresh, &gbits)) return rc;
+    gex = gap_excess(d_gap, r->m, gbits);
+  }
   // gap update mode: log + histogram needs enough work to pay for the partition
-  int mode = 0;
+  int mode = (fresh && gbits == 32 && T < 0xFFFFFFFFll) ? 0 : 1;
   {
     const char *e = getenv("PSG_GAP_MODE");   // "atomic" | "log" | unset = auto
     bool want_log = e ? !strcmp(e, "log") : (T >= (1 << 22));
     if (e && !strcmp(e, "atomic")) want_log = false;
-    if (e && !strcmp(e, "ovf")) { want_log = false; mode = 1; }   // tests: force the overflow-checking atomic kernel
+    if (e && !strcmp(e, "ovf")) { want_log = false; mode = 1; }   // tests: force the carry-checking atomic kernel
     const bool wide = r->m >= 0xFFFFFFFFll || getenv("PSG_LOG_WIDE") != nullptr;   // ranks need more than 32 bits (tests: forced)
-    if (want_log && mode == 0) mode = wide ? 3 : 2;
+    if (want_log) mode = wide ? 3 : 2;
     if (log_out) mode = 2;   // the caller wants the log itself (32-bit ranks: checked by psg_stream_gap_log)
   }
   if (fresh && mode < 2) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));   // the atomics need zeroes; the histogram overwrites
@@ -1186,7 +1191,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     if ((rc = log_d.alloc(K * L * 4))) return rc;   // every entry is written by its chain (0xFFFFFFFF = no entry)
     if (mode == 3 && (rc = loghi_d.alloc(K * L))) return rc;
   }
-  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K, loghi_d.as<u32>()};
+  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K, loghi_d.as<u32>(), gex};
   double kms = 0;
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes
@@ -1246,18 +1251,18 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     *A.nlog_out = K * L;
     log_d.p = nullptr;
   } else if (mode == 2) {
-    if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh))) return rc;
+    if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh, gex))) return rc;
     log_d.alloc(16);   // give the log back to the pool before returning
   } else if (mode == 3) {
-    if ((rc = psg::gap_hist_from_wide_log(log_d, loghi_d, K * L, r->m, d_gap, &hist_ms, fresh))) return rc;
+    if ((rc = psg::gap_hist_from_wide_log(log_d, loghi_d, K * L, r->m, d_gap, &hist_ms, fresh, gex))) return rc;
   }
   st.hist_ms = hist_ms;
-  int ovf = 0;
-  PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), flag_d.p, 4, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
+  u32 xflag = 0;
+  if (gex.hdr) PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), gex.hdr + 2, 4, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
   total_tm.stop();
   PSG_HIP(psg::sync_stream());
-  memcpy(&ovf, pinned_buf(3, 64), 4);
-  if (ovf) { set_error("stream: a 32-bit gap counter overflowed"); return PSG_EOVERFLOW; }
+  if (gex.hdr) memcpy(&xflag, pinned_buf(3, 64), 4);
+  if (xflag) { set_error("stream: excess list capacity exceeded"); return PSG_ECHECK; }
   st.kernel_ms = kms;
   st.total_ms = total_tm.ms();
   note_kernel_ms(kms);

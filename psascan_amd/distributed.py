@@ -148,7 +148,7 @@ class HipA2AOps:
         return out, offs, vb
 
     def hist_slice(self, recv_t, nrecv, base, count):
-        g = self.new_i32(max(count, 1))
+        g = self.new_i32(self.api.gap_words(max(count, 1) - 1))   # a gap array: counters + in-band excess area
         self.api.gap_hist(recv_t.data_ptr(), nrecv, base, count, g.data_ptr())
         return g
 

@@ -191,7 +191,7 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         last_left, last_block_sym = sym(mid - 1), sym(e - 1)
         # ---- step 3: pass A, right half streamed through rank(left BWT) (:403-414)
         rankL = api.rank_build(d_lbwt, ls)
-        gapA = api.DeviceBuffer(4 * (ls + 2))     # fresh gap array: the pass zero-fills / overwrites it
+        gapA = api.gap_array(ls, fill=None)       # fresh gap array: the pass zero-fills / overwrites it
         gtA = api.zeros(4 * ((rs + 31) // 32 + 1))
         scA = search_for(e, [hbL])
         if L.get("initA") is not None:
@@ -226,7 +226,7 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
         # ---- step 5: pass B, the tail streamed through rank(block BWT) (:500-514)
         rankB = api.rank_build(d_bbwt, bs)
         d_bbwt.free()
-        gapB = api.DeviceBuffer(4 * (bs + 2))
+        gapB = api.gap_array(bs, fill=None)
         T = n - e
         _, stB = api.stream_gap(rankB, block_i0, last_block_sym, d_text.at(e), T, gt_cur, 0, gapB, gt_new, max_chains, fresh_gap=True,
                                 search=search_for(e, [hbL, hbR]), tail_begin_abs=e)

@@ -96,7 +96,7 @@ def test_stream_gap_vs_oracle(A, kind, chains):
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_text = A.upload(t, pad_to=16)
     T = n - e
-    d_gap = A.zeros(4 * (m + 2))
+    d_gap = A.gap_array(m)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, chains)
     assert fin == want_fin
@@ -118,7 +118,7 @@ def test_stream_gap_mid_tail_and_accumulate(A):
     want_gap, want_gt, want_fin = orc.stream_pass(rk, i0, t[mid - 1], t, mid, e, gt_in, init)
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_text = A.upload(t, pad_to=16)
-    d_gap = A.upload(np.full(m + 1, 5, np.uint32))
+    d_gap = A.gap_array(m, fill=5)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     fin, st = A.stream_gap(r, i0, t[mid - 1], d_text.at(mid), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, 64)
     assert fin == want_fin and st.n_chains > 8
@@ -139,7 +139,7 @@ def test_stream_gap_log_mode(A, kind, monkeypatch):
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     T = n - e
-    d_gap = A.upload(np.full(m + 1, 3, np.uint32))
+    d_gap = A.gap_array(m, fill=3)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
     fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300)
@@ -161,7 +161,7 @@ def test_stream_gap_chunked_pass(A, monkeypatch, mode):
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
-    d_gap = A.zeros(4 * (m + 2))
+    d_gap = A.gap_array(m)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 16)
     assert fin == want_fin and st.rounds >= (T + 4095) // 4096
@@ -193,7 +193,7 @@ def test_stream_gap_large_block(A, monkeypatch, case):
     gt_in = np.zeros((T + 7) // 8 + 8, np.uint8)
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(lbwt), Lh["i0"], 0, t, mid, n, gt_in, 0)
     r = A.rank_build(Lh["bwt"], mid)
-    d_gap = A.upload(np.full(mid + 1, 0xDEADBEEF if fresh else 2, np.uint32))
+    d_gap = A.gap_array(mid, fill=0xDEADBEEF if fresh else 2)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 4))
     fin, st = A.stream_gap(r, Lh["i0"], 0, d_text.at(mid), T, A.upload(gt_in, pad_to=16), 0, d_gap, d_gtout, 0, fresh_gap=fresh)
     assert fin == want_fin and (st.hist_ms > 0) == ("atomic" not in case)
@@ -269,7 +269,7 @@ def test_stream_gap_wide_log_and_superblocks(A, monkeypatch, kind, fresh):
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     T = n - e
-    d_gap = A.upload(np.full(m + 1, 0xDEADBEEF if fresh else 3, np.uint32))
+    d_gap = A.gap_array(m, fill=0xDEADBEEF if fresh else 3)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
     fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300, fresh_gap=fresh)
@@ -298,12 +298,81 @@ def test_stream_gap_wide_log_chunked_block_layout(A, monkeypatch):
     gt_in = np.zeros((T + 7) // 8 + 8, np.uint8)
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(lbwt), Lh["i0"], 0, t, mid, n, gt_in, 0)
     r = A.rank_build(Lh["bwt"], mid, 32)
-    d_gap = A.zeros(4 * (mid + 2))
+    d_gap = A.gap_array(mid)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 4))
     fin, st = A.stream_gap(r, Lh["i0"], 0, d_text.at(mid), T, A.upload(gt_in, pad_to=16), 0, d_gap, d_gtout, 0)
     assert fin == want_fin and st.hist_ms > 0 and st.rounds >= 3
     assert np.array_equal(A.download(d_gap, np.uint32, mid + 1).astype(np.uint64), want_gap)
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
+# ------------------------------------------------------------------ excess list of the gap counters (a5, a7)
+@pytest.mark.parametrize("kind", ["alla", "sig4z", "skew", "rand255"])
+@pytest.mark.parametrize("mode", ["atomic", "log", "wide"])
+@pytest.mark.parametrize("bits", [8, 16])
+def test_gap_excess_list_with_narrow_counters(A, monkeypatch, kind, mode, bits):
+    """The reference counts in u8 and appends the slot to an excess list whenever a counter wraps (update.hpp:88-96;
+    value = count + 256 * #entries, gap_array.hpp:116-124).  Here the counters are 32 bits wide, so the same path
+    only runs at > 2^32 suffixes per slot; PSG_GAP_COUNTER_BITS narrows them to 8 / 16 bits so that it runs here:
+    atomic and histogram producers, two accumulating passes, then the consumers (values, gap -> bitvector)."""
+    monkeypatch.setenv("PSG_GAP_COUNTER_BITS", str(bits))
+    monkeypatch.setenv("PSG_GAP_MODE", "atomic" if mode == "atomic" else "log")
+    if mode == "wide":
+        monkeypatch.setenv("PSG_LOG_WIDE", "1")
+        monkeypatch.setenv("PSG_LOG_SLAB_SHIFT", "12")
+    n = 120000
+    if kind == "skew":
+        rng = np.random.default_rng(6)
+        t = rng.integers(3, 200, n, dtype=np.uint8)
+        t[n // 3:] = rng.integers(1, 3, n - n // 3, dtype=np.uint8)     # the tail's ranks cluster in a few slots
+    else:
+        t = make_text(kind, n, 9)
+    b, e = 300, 300 + n // 4
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m, T = e - b, n - e
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    assert want_gap.max() >= (1 << bits) or kind != "alla"     # alla: every tail suffix lands in one slot
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    d_gap = A.gap_array(m, fill=None)
+    fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300, fresh_gap=True)
+    assert fin == want_fin
+    cells = A.download(d_gap, np.uint32, m + 1)
+    assert cells.max() < (1 << bits)
+    assert np.array_equal(A.gap_values(d_gap, m), want_gap)
+    d_bv = A.zeros(4 * ((m + T + 31) // 32 + 2))
+    assert A.gap_to_bitvector(d_gap, m, d_bv, m + T) == m + T
+    bv, nb = orc.gap_to_bitvector(want_gap, m)
+    assert np.array_equal(orc.bits(A.download(d_bv, np.uint8, (nb + 7) // 8), nb), orc.bits(bv, nb))
+    # a second pass accumulates on top (same tail again): values double
+    A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300)
+    assert np.array_equal(A.gap_values(d_gap, m), 2 * want_gap)
+
+
+@pytest.mark.parametrize("bits", [8, 16, 32])
+def test_split_gap_with_values_beyond_the_counter_width(A, bits):
+    """compute_right_gap / compute_left_gap on a block gap whose values exceed the counters (the reference widens to
+    u16 and replays the excess, gap_array.hpp:386-529): 255, 256, 65535, 70000, 131079 and -- with the production
+    width -- 2^32 + 5; checked against the oracle, which is pinned against the reference on the same shapes."""
+    ml, mr = 4000, 2400
+    bs = ml + mr
+    rng = np.random.default_rng(8)
+    bvb = rng.permutation(np.array([0] * ml + [1] * mr, np.uint8))
+    bv = np.concatenate([orc.packbits(bvb), np.zeros(8, np.uint8)])
+    gap = rng.integers(0, 3, bs + 1).astype(np.uint64)
+    gap[3] = 255; gap[4] = 256; gap[10] = 70000; gap[11] = 65535; gap[64] = 131072 + 7; gap[bs] = 300
+    if bits == 32:
+        gap[2000] = 2 ** 32 + 5; gap[5000] = 2 ** 33 + 1
+    T = int(gap.sum())
+    d_gap = A.gap_array_from_values(gap, bits)
+    assert np.array_equal(A.gap_values(d_gap, bs), gap)
+    d_bv = A.upload(bv, pad_to=8)
+    mbvL = A.DeviceBuffer(4 * ((bs + T + 31) // 32 + 1))
+    mbvR = A.DeviceBuffer(4 * ((mr + T + 31) // 32 + 1))
+    A.split_gap(d_gap, d_bv, ml, mr, T, mbvL, mbvR)
+    assert np.array_equal(A.download(A.mbv_to_gap(mbvL, bs + T, ml), np.uint64, ml + 1), orc.left_gap(gap, bv, ml, mr))
+    assert np.array_equal(A.download(A.mbv_to_gap(mbvR, mr + T, mr), np.uint64, mr + 1), orc.right_gap(gap, bv, ml, mr))
 
 
 # ------------------------------------------------------------------ K8: start ranks by string search (a14)
@@ -378,7 +447,7 @@ def test_stream_gap_repetitive_text_resolves_in_one_round(A, monkeypatch, kind, 
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
     psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e)
     sc = A.search_ctx(d_text, n, e, A.upload(_gt_cmp_end_bits(isa, n, e), pad_to=8), [(b, m, A.upload(psa.astype(np.uint32)), None)])
-    d_gap = A.zeros(4 * (m + 2))
+    d_gap = A.gap_array(m)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     with pytest.raises(PsgError) as ei:
         A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 96, fail_if_unresolved=True)
@@ -430,7 +499,7 @@ def test_stream_gap_ex_contract(A, gpu_lib):
     m = 2000
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
-    d_gap = A.upload(np.full(m + 1, 0xABCD1234, np.uint32))
+    d_gap = A.gap_array(m, fill=0xABCD1234)
     fin, st = C.c_int64(0), StreamStatsC()
     rc = gpu_lib.psg_stream_gap_ex(r.h, i0, int(t[2099]), d_text.at(2100), 2900, 0, d_gtin.ptr, init, d_gap.ptr, None, 0, 6, C.byref(fin), C.byref(st))
     assert rc != 0 and b"flag" in gpu_lib.psg_last_error()
@@ -450,18 +519,18 @@ def test_stream_gap_overflow_checking_mode(A, monkeypatch):
     want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
-    d_gap = A.zeros(4 * (m + 2))
+    d_gap = A.gap_array(m)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
     fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 100)
     assert fin == want_fin and st.hist_ms == 0
     assert np.array_equal(A.download(d_gap, np.uint32, m + 1).astype(np.uint64), want_gap)
-    # a counter at 2^32-1 must be reported, not wrapped silently
-    from psascan_amd._lib import PsgError
+    # a counter at 2^32-1 keeps counting: it wraps and leaves a carry in the excess list (gap_array.hpp:79-88)
     hot = int(np.argmax(want_gap))
-    g = np.zeros(m + 1, np.uint32); g[hot] = 0xFFFFFFFF
-    with pytest.raises(PsgError) as ei:
-        A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, A.upload(g), d_gtout, 100)
-    assert ei.value.code == -4
+    g = np.zeros(m + 1, np.uint64); g[hot] = 0xFFFFFFFF
+    d_g = A.gap_array_from_values(g)
+    A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_g, d_gtout, 100)
+    assert np.array_equal(A.gap_values(d_g, m), want_gap + g)
+    assert int(A.download(d_g, np.uint32, m + 1)[hot]) == (0xFFFFFFFF + int(want_gap[hot])) & 0xFFFFFFFF
 
 
 @pytest.mark.parametrize("m,nlog,skew", [(100, 5000, 0), (66666, 133504, 0), (70000, 300, 0), (1 << 20, 1 << 22, 0),
@@ -485,7 +554,7 @@ def test_gap_hist_from_log(A, gpu_lib, m, nlog, skew):
     assert np.array_equal(A.download(d_gap, np.uint32, m + 1), want)
 
 
-W = 16384   # counters per histogram window (gap_hist.hip: WSIZE)
+W = 32768   # counters per histogram window (gap_hist.hip: WSIZE)
 
 
 @pytest.mark.parametrize("nwin_m1", [511, 512, 513, 1023, 1024, 1025, 1533, 1534, 1535, 2556, 2557, 4000])
@@ -578,7 +647,7 @@ def test_multi_gpu_building_blocks(A, kind, nparts):
 def test_stream_gap_empty_tail(A):
     bwt = np.array([0, 1, 2, 1], np.uint8)
     r = A.rank_build(A.upload(bwt, pad_to=16), 4)
-    d_gap = A.zeros(32)
+    d_gap = A.gap_array(4)
     fin, _ = A.stream_gap(r, 0, 1, None, 0, None, 3, d_gap, None)
     assert fin == 3
     assert not A.download(d_gap, np.uint32, 5).any()
@@ -604,7 +673,7 @@ def test_block_steps_vs_oracle(A, kind):
     gapB, _, _ = orc.stream_pass(orc.Rank(bbwt), bi0, t[e - 1], t, e, n, gt_in, 0)
     rg, lg = orc.right_gap(gapB, bv, ml, mr), orc.left_gap(gapB, bv, ml, mr)
     # device
-    d_gapA = A.upload(gapA.astype(np.uint32))
+    d_gapA = A.gap_array_from_values(gapA)
     d_bv = A.zeros(4 * ((bs + 31) // 32 + 2))
     assert A.gap_to_bitvector(d_gapA, ml, d_bv, bs) == bs
     assert np.array_equal(orc.bits(A.download(d_bv, np.uint8, (bs + 7) // 8), bs), orc.bits(bv, bs))
@@ -612,7 +681,7 @@ def test_block_steps_vs_oracle(A, kind):
     got_i0 = A.merge_bwt(A.upload(lbwt, 16), A.upload(rbwt, 16), ml, mr, li0, ri0, t[mid - 1], d_bv, d_out)
     assert got_i0 == bi0
     assert np.array_equal(A.download(d_out, np.uint8, bs), bbwt)
-    d_gapB = A.upload(gapB.astype(np.uint32))
+    d_gapB = A.gap_array_from_values(gapB)
     mbvL = A.DeviceBuffer(4 * ((bs + T + 31) // 32 + 1))
     mbvR = A.DeviceBuffer(4 * ((mr + T + 31) // 32 + 1))
     A.split_gap(d_gapB, d_bv, ml, mr, T, mbvL, mbvR)

@@ -23,7 +23,7 @@ for rep in range(2):     # the first round pays for hipMalloc (the pool is empty
     # pass A: right half through rank(left BWT); rank at the tail end via a full stream of [e, n) is not needed here:
     # use the device path with a right context on [mid, e) (tail of pass A ends at e < n)
     rkL = api.rank_build(L["bwt"], half)
-    gapA = api.DeviceBuffer(4 * (half + 2)); gtA = api.zeros(4 * (half // 32 + 4))
+    gapA = api.gap_array(half, fill=None); gtA = api.zeros(4 * (half // 32 + 4))
     from psascan_amd import distributed as D
     ctx = D.context_len(e, n)
     gt_in = api.zeros(4 * ((half + ctx) // 32 + 4))          # gt of the right half w.r.t. e: from the sorter, shifted by ctx
@@ -35,7 +35,7 @@ for rep in range(2):     # the first round pays for hipMalloc (the pool is empty
     bbwt = api.DeviceBuffer(2 * half + 16)
     bi0 = timed("K4 merge_bwt", lambda: api.merge_bwt(L["bwt"], R["bwt"], half, half, L["i0"], R["i0"], text_mid, bv, bbwt), 2 * half)
     rkB = timed("K1 rank build (block BWT)", lambda: api.rank_build(bbwt, 2 * half), 2 * half)
-    gapB = api.DeviceBuffer(4 * (2 * half + 2)); gtB = api.zeros(4 * ((n - e) // 32 + 4))
+    gapB = api.gap_array(2 * half, fill=None); gtB = api.zeros(4 * ((n - e) // 32 + 4))
     gt0 = api.zeros(4 * ((n - e) // 32 + 4))
     finB, stB = timed("pass B stream (tail through block)", lambda: api.stream_gap(rkB, bi0, text_e, d_text.at(e), n - e, gt0, 0, gapB, gtB, 0, fresh_gap=True), n - e)
     rkB.free()

@@ -5,9 +5,9 @@ import psascan_amd
 from psascan_amd import api, extras
 L = psascan_amd.lib()
 m = 1 << 31
-gap = api.zeros(4 * (m + 2))
+gap = api.gap_array(m)
 L.psg_memset(gap.ptr, 1, 4 * (m + 1))     # every counter = 0x01010101 is too big; use a kernel-free trick: bytes 1 -> value 16843009
-L.psg_memset(gap.ptr, 0, 4 * (m + 2))
+L.psg_memset(gap.ptr, 0, 4 * api.gap_words(m))
 one = api.upload(np.ones(1 << 20, np.uint32))
 for k in range(0, m, 1 << 20):
     L.psg_d2d(gap.ptr + 4 * k, one.ptr, 4 << 20)
