@@ -265,6 +265,27 @@ typedef struct {
 int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slice_entries, psg_merge_check *check,
                      psg_sink_fn sink, void *sink_ctx, psg_merge_stream_stats *stats);
 
+/* ---- block-per-GPU schedule (psascan_amd/blockdist.py): pieces of the final merge when
+ *      every half-block's merge bitvector and partial SA live on the rank that owns the block and every rank
+ *      merges one range of the output.                                                                         */
+/* h_ones[k] = number of one bits in d_bits[0 .. h_pos[k]) (rank1; ranksel_support.hpp:45-187), 0 <= pos <= nbits */
+int psg_bits_rank1(const uint32_t *d_bits, int64_t nbits, const int64_t *h_pos, int64_t count, int64_t *h_ones);
+/* A merge plan over SLICES: of every level only the part this rank's output range [out_begin, out_end) touches is
+ * present.  Level h: d_mbv_words holds the words [first_word, first_word + n_words) of the level's merge bitvector,
+ * first_word a multiple of 128 (a 4096-bit group), ones_before = one bits in front of that word; d_psa_lo (and
+ * d_psa_hi) hold the elements [psa_first, psa_first + psa_count) of the half-block's partial SA.  psg_merge_run on
+ * the plan accepts output ranges inside [out_begin, out_end).                                                   */
+typedef struct {
+  int64_t beg, size;             /* the half-block                                                   */
+  int64_t nbits;                 /* length of the level's merge bitvector (0 for the last level)       */
+  const uint32_t *d_mbv_words;   /* NULL for the last level                                            */
+  int64_t first_word, n_words, ones_before;
+  const uint32_t *d_psa_lo;
+  const uint8_t *d_psa_hi;       /* may be NULL                                                       */
+  int64_t psa_first, psa_count;
+} psg_hb_slice_desc;
+int psg_merge_plan_create_sliced(const psg_hb_slice_desc *levels, int H, psg_merge_plan_t **out);
+
 /* ---- multi-GPU building blocks: one pass sharded over the TAIL (the reference's own parallel
  *      axis, compute_gap.hpp:68-69,114-124), the gap array sharded by index range.  Each rank
  *      streams its tail range into a rank log, the logs are exchanged so that every rank holds

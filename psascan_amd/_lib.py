@@ -51,6 +51,12 @@ class StreamArgsC(C.Structure):
                 ("search", C.POINTER(SearchCtxC)), ("tail_begin_abs", C.c_int64)]
 
 
+class HbSliceDescC(C.Structure):
+    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("nbits", C.c_int64), ("d_mbv_words", C.c_void_p), ("first_word", C.c_int64),
+                ("n_words", C.c_int64), ("ones_before", C.c_int64), ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p),
+                ("psa_first", C.c_int64), ("psa_count", C.c_int64)]
+
+
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
 
 # every symbol include/psascan_amd.h declares: name -> (restype, argtypes)
@@ -97,6 +103,8 @@ SIGNATURES = {
     "psg_merge_plan_create": (_int, [C.POINTER(HbDescC), _int, C.POINTER(_vp)]),
     "psg_merge_run": (_int, [_vp, _i64, _i64, _vp]),
     "psg_merge_plan_free": (None, [_vp]),
+    "psg_bits_rank1": (_int, [_vp, _i64, C.POINTER(_i64), _i64, C.POINTER(_i64)]),
+    "psg_merge_plan_create_sliced": (_int, [C.POINTER(HbSliceDescC), _int, C.POINTER(_vp)]),
     "psg_merge_stream": (_int, [C.POINTER(HbHostDescC), _int, _i64, C.POINTER(MergeCheckC), SINK_FN, _vp, C.POINTER(MergeStreamStatsC)]),
     "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
     "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (HbDescC, HbHostDescC, MergeCheckC, MergeStreamStatsC, SINK_FN, SearchCtxC, StreamArgsC, StreamStatsC, check, lib)
+from ._lib import (HbDescC, HbHostDescC, HbSliceDescC, MergeCheckC, MergeStreamStatsC, SINK_FN, SearchCtxC, StreamArgsC, StreamStatsC, check, lib)
 
 
 class DeviceBuffer:
@@ -270,6 +270,32 @@ class MergePlan:
             self.free()
         except Exception:
             pass
+
+
+def bits_rank1(d_bits, nbits, positions):
+    """ones in d_bits[0 .. pos) for every pos (rank1 of ranksel_support.hpp:45-187)"""
+    pos = np.ascontiguousarray(positions, np.int64)
+    out = np.zeros(len(pos), np.int64)
+    check(lib().psg_bits_rank1(_ptr(d_bits), nbits, pos.ctypes.data_as(C.POINTER(C.c_int64)), len(pos), out.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
+
+
+class SlicedMergePlan(MergePlan):
+    """merge plan over slices of the levels (block-per-GPU schedule): levels = dicts with beg, size, nbits, d_mbv
+    (device pointer or None), first_word, n_words, ones_before, d_psa (device pointer or None), psa_first, psa_count."""
+
+    def __init__(self, levels):
+        H = len(levels)
+        arr = (HbSliceDescC * H)()
+        for k, lv in enumerate(levels):
+            arr[k].beg, arr[k].size, arr[k].nbits = lv["beg"], lv["size"], lv["nbits"]
+            arr[k].d_mbv_words, arr[k].first_word, arr[k].n_words, arr[k].ones_before = _ptr(lv["d_mbv"]), lv["first_word"], lv["n_words"], lv["ones_before"]
+            arr[k].d_psa_lo, arr[k].d_psa_hi, arr[k].psa_first, arr[k].psa_count = _ptr(lv["d_psa"]), None, lv["psa_first"], lv["psa_count"]
+        self._keep = levels
+        self.n = sum(lv["size"] for lv in levels)
+        h = C.c_void_p()
+        check(lib().psg_merge_plan_create_sliced(arr, H, C.byref(h)))
+        self.h = h.value
 
 
 def merge_half_blocks(half_blocks, d_out=None):

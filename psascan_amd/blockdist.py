@@ -1,0 +1,310 @@
+"""Block-per-GPU schedule (north_star's multi-GPU split).
+
+One process per GPU (torch.distributed: "nccl" = RCCL over xGMI on the node, "gloo" in the CPU tests and the
+shared-GPU rehearsal).  The text is cut into `world` blocks, rank g owns block g = [b_g, e_g):
+
+  local phase   sort the two halves, pass A (right half through the left half's rank), gap -> bitvector, BWT
+                merge, rank over the block BWT -- process_block's steps 1-4 (partial_sufsort.hpp:166-500), no
+                communication.  Product: the rank structure of the block, and the block's OWN gt slice: bits
+                [text[j..) > text[b_g..)] for j in (b_g, e_g].
+  rounds        round r = 1 .. world-1: ONE all-gather of the gt slice every rank produced in round r-1, then
+                rank g streams chunk q = g + r (the text of block q) through its rank structure into its gap array
+                (compute_gap, partial_sufsort.hpp:512-514).  The gt bits it needs -- [text[j..) > text[e_g..)] for
+                j in chunk q -- are exactly what rank g+1 produced one round earlier while streaming the same chunk
+                (stream.hpp:150, handed over at partial_sufsort.hpp:573-579); in round 1 they are rank g+1's own
+                slice.  The pass writes the next slice.  Chunks are streamed near-to-far, so the start rank of a
+                chunk (rank of the suffix at the chunk's end among the block's suffixes) does not come from the
+                previous pass: it is found by string search over the block's partial SAs before the rounds
+                (em_compute_initial_ranks.hpp:222-319).
+  split         the block gap is split into the two halves' merge bitvectors (partial_sufsort.hpp:536-542).
+  merge         output-range partition (merge.hpp:55-180 in closed form): rank d produces the entries
+                [X_d, X_{d+1}) of the suffix array.  The positions every level's walk reaches at the range
+                boundaries are computed level by level by the owner of the level (one small broadcast each); then
+                ONE all-to-all brings every rank the slices of the merge bitvectors and partial SAs its range
+                touches, and the merge runs locally on a plan over slices (psg_merge_plan_create_sliced).
+
+`ops` supplies the compute: HipBlockOps = the C ABI on this rank's GPU; the CPU tests inject oracle-backed
+stand-ins to check the schedule, the indexing of the exchanged bits and the slice arithmetic without a GPU.
+"""
+import numpy as np
+
+
+def block_bounds(n, world):
+    """[b_0 = 0, b_1, ..., b_world = n]: equal blocks, every block at least two symbols"""
+    bs = -(-n // world)
+    bounds = [min(n, g * bs) for g in range(world)] + [n]
+    if any(bounds[g + 1] - bounds[g] < 2 for g in range(world)):
+        raise ValueError(f"text of {n} symbols is too short for {world} blocks")
+    return bounds
+
+
+def output_cuts(n, world):
+    return [min(n, (n * r // world + 4095) // 4096 * 4096) for r in range(world)] + [n]
+
+
+def slice_words(bounds):
+    """int32 words of a gt slice (one bit per position of the largest block, padded)"""
+    return (max(bounds[g + 1] - bounds[g] for g in range(len(bounds) - 1)) + 31) // 32 + 4
+
+
+def run(dist, ops, world, rank, n, stats=None):
+    """The whole schedule on this rank.  Returns (x0, x1, sa5 bytes of the output entries [x0, x1))."""
+    bounds = block_bounds(n, world)
+    b, e = bounds[rank], bounds[rank + 1]
+    mid = b + (e - b) // 2
+    words = slice_words(bounds)
+    st = ops.local_block(b, mid, e, words)                      # -> state with .own_gt (int32 tensor of `words`)
+    # start ranks of the chunks this rank will stream: rank of text[e_q..) among the block's suffixes
+    chunk_ends = [bounds[q + 1] for q in range(rank + 1, world)]
+    start = ops.start_ranks(st, chunk_ends) if chunk_ends else []
+    prev = st.own_gt
+    for r in range(1, world):
+        gathered = [ops.new_i32(words) for _ in range(world)]
+        if world > 1:
+            ops.before_collective()
+            dist.all_gather(gathered, prev)                     # the ONE collective of the round
+            ops.after_collective()
+        q = rank + r
+        if q < world:
+            prev = ops.stream(st, bounds[q], bounds[q + 1], gathered[rank + 1], int(start[q - rank - 1]), words, first=(r == 1))
+            if stats is not None:
+                stats.append((rank, q, getattr(st, "last_stats", None)))
+        else:
+            prev = ops.new_i32(words)
+    hbs = ops.finish(st, n - e)                                 # [{beg, size, mbv, nbits, psa}] left half, right half
+    return merge_ranges(dist, ops, world, rank, n, bounds, hbs)
+
+
+def merge_ranges(dist, ops, world, rank, n, bounds, my_hbs):
+    """Output-range partitioned merge.  my_hbs: this rank's two half-blocks (mbv = None for the very last one)."""
+    H = 2 * world
+    sizes = []
+    for g in range(world):
+        b, e = bounds[g], bounds[g + 1]
+        mid = b + (e - b) // 2
+        sizes += [(b, mid - b), (mid, e - mid)]
+    later = [0] * (H + 1)
+    for h in range(H - 1, -1, -1):
+        later[h] = later[h + 1] + sizes[h][1]
+    nbits = [later[h] if h + 1 < H else 0 for h in range(H)]     # level h: own elements + everything behind it
+    X = output_cuts(n, world)
+    nb = len(X)
+    # ---- positions of the range boundaries on every level: q_0 = X, q_{h+1} = rank1(mbv_h, q_h)
+    q = np.array(X, np.int64)
+    qs, ones_al, cur = [], [], []
+    for h in range(H):
+        qs.append(q.copy())
+        if h == H - 1:
+            cur.append(q.copy())
+            ones_al.append(np.zeros(nb, np.int64))
+            break
+        t = ops.new_i64(2 * nb)
+        if h // 2 == rank:
+            hb = my_hbs[h % 2]
+            qa = (q // 4096) * 4096
+            r1 = ops.rank1(hb["mbv"], nbits[h], np.concatenate([q, qa]))
+            t = ops.i64_from(r1)
+        if world > 1:
+            ops.before_collective()
+            dist.broadcast(t, src=h // 2)
+            ops.after_collective()
+        r1 = ops.to_numpy_i64(t)
+        ones, oa = r1[:nb], r1[nb:]
+        cur.append(q - ones)
+        ones_al.append(oa)
+        q = ones
+    for h in range(H):
+        assert cur[h][0] == 0 and cur[h][-1] == sizes[h][1], (h, cur[h], sizes[h])
+    # ---- what dest d gets of level h: mbv words [fw, lw) and PSA elements [c0, c1)
+    def piece(h, d):
+        c0, c1 = int(cur[h][d]), int(cur[h][d + 1])
+        if h == H - 1:
+            return 0, 0, c0, c1
+        q0, q1 = int(qs[h][d]), int(qs[h][d + 1])
+        total_words = (nbits[h] + 31) // 32
+        fw = min((q0 // 4096) * 128, total_words)
+        lw = min(total_words, (q1 + 31) // 32 + 1)          # + 1: a 32-bit fetch at the range end may look one word ahead
+        return fw, max(fw, lw), c0, c1
+
+    send_parts, send_sizes = [], []
+    for d in range(world):
+        tot = 0
+        for k in (0, 1):
+            h = 2 * rank + k
+            fw, lw, c0, c1 = piece(h, d)
+            hb = my_hbs[k]
+            if lw > fw:
+                send_parts.append(ops.mbv_words(hb["mbv"], fw, lw - fw))
+            if c1 > c0:
+                send_parts.append(ops.psa_words(hb["psa"], c0, c1 - c0))
+            tot += (lw - fw) + (c1 - c0)
+        send_sizes.append(tot)
+    recv_sizes = []
+    for src in range(world):
+        tot = 0
+        for k in (0, 1):
+            fw, lw, c0, c1 = piece(2 * src + k, rank)
+            tot += (lw - fw) + (c1 - c0)
+        recv_sizes.append(tot)
+    send_t = ops.cat_i32(send_parts, sum(send_sizes))
+    recv_t = ops.new_i32(max(1, sum(recv_sizes)))
+    if world > 1:
+        ops.before_collective()
+        dist.all_to_all_single(recv_t[: sum(recv_sizes)], send_t[: sum(send_sizes)], recv_sizes, send_sizes)
+        ops.after_collective()
+    else:
+        recv_t = send_t
+    # ---- local merge over the slices
+    levels, off = [], 0
+    for h in range(H):
+        fw, lw, c0, c1 = piece(h, rank)
+        lv = {"beg": sizes[h][0], "size": sizes[h][1], "nbits": nbits[h], "first_word": fw, "n_words": lw - fw,
+              "ones_before": int(ones_al[h][rank]), "psa_first": c0, "psa_count": c1 - c0, "mbv_off": off, "psa_off": off + (lw - fw)}
+        off += (lw - fw) + (c1 - c0)
+        levels.append(lv)
+    x0, x1 = X[rank], X[rank + 1]
+    out = ops.merge_slices(levels, recv_t, x0, x1)
+    return x0, x1, out
+
+
+class HipBlockOps:
+    """The schedule's compute on this rank's GPU through the C ABI.  comm = "cuda": tensors handed to the
+    collectives are torch CUDA tensors (NCCL/RCCL; the library is put on torch's stream by the caller);
+    comm = "cpu": CPU tensors (gloo; data is staged through the library's copies -- shared-GPU rehearsal)."""
+
+    def __init__(self, torch, api, d_text, n, sorter, comm="cuda", max_chains=0, host_text=None):
+        self.torch, self.api, self.d_text, self.n, self.sorter, self.comm, self.max_chains = torch, api, d_text, n, sorter, comm, max_chains
+        self.host_text = host_text
+
+    # ---- tensors
+    def new_i32(self, k):
+        return self.torch.zeros(int(k), dtype=self.torch.int32, device=self.comm)
+
+    def new_i64(self, k):
+        return self.torch.zeros(int(k), dtype=self.torch.int64, device=self.comm)
+
+    def i64_from(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(self.comm)
+
+    def to_numpy_i64(self, t):
+        return t.cpu().numpy().astype(np.int64)
+
+    def cat_i32(self, parts, total):
+        return self.torch.cat(parts) if parts else self.new_i32(1)
+
+    def before_collective(self):
+        self.api.sync()
+        if self.comm == "cuda":
+            self.torch.cuda.synchronize()
+
+    def after_collective(self):
+        if self.comm == "cuda":
+            self.torch.cuda.synchronize()
+
+    def _to_dev(self, t, nwords):
+        """device pointer of an int32 tensor's first nwords (uploads CPU tensors)"""
+        if self.comm == "cuda":
+            return t, t.data_ptr()
+        buf = self.api.upload(t[:nwords].numpy(), pad_to=16)
+        return buf, buf.ptr
+
+    def _from_dev(self, buf_or_ptr, nwords):
+        """int32 tensor of nwords from a device buffer"""
+        a = self.api.download(buf_or_ptr, np.int32, nwords)
+        return self.torch.from_numpy(a).to(self.comm)
+
+    def sym(self, pos):
+        return int(self.api.download(self.d_text, np.uint8, 1, pos)[0])
+
+    # ---- local phase
+    def local_block(self, b, mid, e, words):
+        api, n = self.api, self.n
+        ls, rs, bs = mid - b, e - mid, e - b
+
+        class State:
+            pass
+        st = State()
+        st.b, st.mid, st.e = b, mid, e
+        R = self.sorter(None, mid, e, None)
+        L = self.sorter(None, b, mid, None)
+        st.L, st.R = L, R
+        st.last_left, st.last = self.sym(mid - 1), self.sym(e - 1)
+        rankL = api.rank_build(L["bwt"], ls)
+        gapA = api.gap_array(ls, fill=None)
+        gtA = api.zeros(4 * ((rs + 31) // 32 + 4))
+        scA = api.search_ctx(self.d_text, n, n, None, [(b, ls, L["psa_lo"], None)])     # direct comparison to the end of the text
+        initA = int(api.initial_ranks(scA, [e])[0])
+        api.stream_gap(rankL, L["i0"], st.last_left, self.d_text.at(mid), rs, R["gt_begin"], initA, gapA, gtA, self.max_chains, fresh_gap=True)
+        rankL.free()
+        st.bvA = api.zeros(4 * ((bs + 31) // 32 + 2))
+        assert api.gap_to_bitvector(gapA, ls, st.bvA, bs) == bs
+        gapA.free()
+        own = api.zeros(4 * words)
+        api.bitcopy(own, 0, gtA, 0, rs)                       # positions (mid, e]: u = e - j
+        api.bitcopy(own, rs, L["gt_begin"], 0, ls)            # positions (b, mid]
+        st.own_gt = self._from_dev(own, words)
+        st.rank = None
+        if e < n:                                             # not the last block: it will be streamed through
+            d_bbwt = api.DeviceBuffer(bs + 16)
+            st.block_i0 = api.merge_bwt(L["bwt"], R["bwt"], ls, rs, L["i0"], R["i0"], st.last_left, st.bvA, d_bbwt)
+            st.rank = api.rank_build(d_bbwt, bs)
+            d_bbwt.free()
+            st.gap = api.gap_array(bs, fill=None)
+        return st
+
+    def start_ranks(self, st, positions):
+        sc = self.api.search_ctx(self.d_text, self.n, self.n, None, [(st.b, st.mid - st.b, st.L["psa_lo"], None), (st.mid, st.e - st.mid, st.R["psa_lo"], None)])
+        return self.api.initial_ranks(sc, positions)
+
+    def stream(self, st, cb, ce, gt_in_t, start_rank, words, first):
+        api = self.api
+        T = ce - cb
+        keep, gin = self._to_dev(gt_in_t, (T + 31) // 32 + 1)
+        gout = api.zeros(4 * words)
+        _, s = api.stream_gap(st.rank, st.block_i0, st.last, self.d_text.at(cb), T, gin, start_rank, st.gap, gout, self.max_chains, fresh_gap=first)
+        st.last_stats = s
+        return self._from_dev(gout, words)
+
+    def finish(self, st, T):
+        api = self.api
+        ls, rs, bs = st.mid - st.b, st.e - st.mid, st.e - st.b
+        L = {"beg": st.b, "size": ls, "psa": st.L["psa_lo"], "mbv": None, "nbits": 0}
+        R = {"beg": st.mid, "size": rs, "psa": st.R["psa_lo"], "mbv": None, "nbits": 0}
+        if st.rank is None:                                   # last block: the left half's gap is its merge bitvector
+            L["mbv"], L["nbits"] = st.bvA, bs
+            return [L, R]
+        st.rank.free()
+        mbvL = api.DeviceBuffer(4 * ((bs + T + 31) // 32 + 2))
+        mbvR = api.DeviceBuffer(4 * ((rs + T + 31) // 32 + 2))
+        api.split_gap(st.gap, st.bvA, ls, rs, T, mbvL, mbvR)
+        st.gap.free()
+        L["mbv"], L["nbits"], R["mbv"], R["nbits"] = mbvL, bs + T, mbvR, rs + T
+        return [L, R]
+
+    # ---- merge
+    def rank1(self, mbv, nbits, positions):
+        return self.api.bits_rank1(mbv, nbits, positions)
+
+    def mbv_words(self, mbv, first_word, n_words):
+        if self.comm == "cuda":
+            t = self.torch.empty(n_words, dtype=self.torch.int32, device="cuda")
+            self.api.check(self.api.lib().psg_d2d(t.data_ptr(), mbv.ptr + 4 * first_word, 4 * n_words))
+            self.api.sync()
+            return t
+        return self.torch.from_numpy(self.api.download(mbv, np.int32, n_words, 4 * first_word))
+
+    def psa_words(self, psa, first, count):
+        return self.mbv_words(psa, first, count)
+
+    def merge_slices(self, levels, recv_t, x0, x1):
+        api = self.api
+        keep, base = self._to_dev(recv_t, recv_t.numel())
+        descs = []
+        for lv in levels:
+            descs.append(dict(lv, d_mbv=(base + 4 * lv["mbv_off"]) if lv["n_words"] else None, d_psa=(base + 4 * lv["psa_off"]) if lv["psa_count"] else None))
+        plan = api.SlicedMergePlan(descs)
+        d_out = api.DeviceBuffer(5 * (x1 - x0) + 16)
+        plan.run(x0, x1 - x0, d_out)
+        plan.free()
+        self.d_out = d_out
+        return api.download(d_out, np.uint8, 5 * (x1 - x0))

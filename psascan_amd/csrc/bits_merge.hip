@@ -805,6 +805,89 @@ extern "C" int psg_merge_run(const psg_merge_plan_t *p, int64_t out_begin, int64
 }
 
 // =======================================================================================
+// block-per-GPU schedule: rank queries on a merge bitvector, merge plan over slices
+// =======================================================================================
+// ones[k] = popcount of bits [0, pos[k]): samples per 4096-bit group + partial popcount.  Block k, 128 threads.
+__global__ __launch_bounds__(128) void bits_rank1_kernel(const u32 *bits, i64 nbits, const u64 *samp, const i64 *pos, i64 *ones, i64 total) {
+  __shared__ u32 red[2];
+  const i64 q = pos[blockIdx.x];
+  if (q >= nbits) { if (threadIdx.x == 0) ones[blockIdx.x] = total; return; }
+  const i64 g = q >> 12, gbase = g << 12;
+  u32 part = 0;
+  const i64 wb = gbase + (i64)threadIdx.x * 32;
+  if (wb < q) { u32 w = gload(bits + (wb >> 5)); const i64 nb = q - wb; if (nb < 32) w &= (1u << nb) - 1u; part = __popc(w); }
+  const u32 inc = wave_incl_scan(part);
+  if (lane_id() == 63) red[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) ones[blockIdx.x] = (i64)samp[g] + red[0] + red[1];
+}
+
+extern "C" int psg_bits_rank1(const uint32_t *d_bits, int64_t nbits, const int64_t *h_pos, int64_t count, int64_t *h_ones) {
+  PSG_REQUIRE(d_bits && nbits >= 0 && h_pos && h_ones && count >= 0, "psg_bits_rank1");
+  if (count == 0) return 0;
+  for (i64 k = 0; k < count; ++k) PSG_REQUIRE(h_pos[k] >= 0 && h_pos[k] <= nbits, "psg_bits_rank1: position out of range");
+  const i64 ntiles = std::max<i64>(1, cdiv(nbits, TILE_B));
+  DevBuf samp, tot, pos, out;
+  int rc;
+  if ((rc = samp.alloc((ntiles + 1) * 8)) || (rc = tot.alloc(8)) || (rc = pos.alloc(count * 8)) || (rc = out.alloc(count * 8))) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_bits, nbits, samp.as<u64>());
+  if ((rc = scan_u64_inplace(samp.as<u64>(), ntiles, tot.as<u64>()))) return rc;
+  u64 total = 0;
+  if ((rc = psg::copy_d2h(&total, tot.p, 8))) return rc;
+  if ((rc = psg::copy_h2d(pos.p, h_pos, (size_t)count * 8))) return rc;
+  hipLaunchKernelGGL(bits_rank1_kernel, dim3((unsigned)count), dim3(128), 0, stream(), d_bits, nbits, samp.as<u64>(), pos.as<i64>(), out.as<i64>(), (i64)total);
+  PSG_HIP(hipGetLastError());
+  return psg::copy_d2h(h_ones, out.p, (size_t)count * 8);
+}
+
+// absolute rank samples of a slice: samp[g] += ones_before for every group of the slice
+__global__ __launch_bounds__(PSG_WG) void add_const_u64_kernel(u64 *v, i64 n, u64 c) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k < n) v[k] += c;
+}
+
+extern "C" int psg_merge_plan_create_sliced(const psg_hb_slice_desc *lv, int H, psg_merge_plan_t **out) {
+  PSG_REQUIRE(lv && H >= 1 && out, "psg_merge_plan_create_sliced");
+  psg_merge_plan *p = new psg_merge_plan();
+  p->H = H;
+  int rc = 0;
+  i64 n = 0;
+  for (int h = 0; h < H; ++h) {
+    const psg_hb_slice_desc &D = lv[h];
+    if (D.size < 1 || D.psa_first < 0 || D.psa_count < 0 || D.psa_first + D.psa_count > D.size || (D.psa_count > 0 && !D.d_psa_lo) ||
+        (h + 1 < H && D.n_words > 0 && (!D.d_mbv_words || (D.first_word & 127) != 0 || D.first_word < 0))) {
+      psg_merge_plan_free(p); set_error("psg_merge_plan_create_sliced: bad level " + std::to_string(h)); return PSG_EINVAL;
+    }
+    n += D.size;
+    MergeLevel L{};
+    L.beg = D.beg; L.size = D.size;
+    L.lo = D.d_psa_lo ? D.d_psa_lo - D.psa_first : nullptr;       // absolute element indices land inside the slice
+    L.hi = D.d_psa_hi ? D.d_psa_hi - D.psa_first : nullptr;
+    if (h + 1 < H) {
+      L.nbits = D.nbits;
+      L.mbv = D.d_mbv_words ? D.d_mbv_words - D.first_word : nullptr;
+      const i64 slice_bits = D.n_words * 32, ntiles = std::max<i64>(1, cdiv(slice_bits, TILE_B));
+      void *samp = nullptr;
+      if (psg::pool_alloc(&samp, (size_t)(ntiles + 1) * 8) != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
+      p->owned.push_back(samp);
+      if (D.n_words > 0) {
+        hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), D.d_mbv_words, slice_bits, (u64 *)samp);
+        if ((rc = scan_u64_inplace((u64 *)samp, ntiles, nullptr))) { psg_merge_plan_free(p); return rc; }
+        hipLaunchKernelGGL(add_const_u64_kernel, dim3((unsigned)cdiv(ntiles, PSG_WG)), dim3(PSG_WG), 0, stream(), (u64 *)samp, ntiles, (u64)D.ones_before);
+      }
+      L.samp = (const u64 *)samp - (D.first_word >> 7);            // one sample per 4096 bits = 128 words
+    }
+    p->levels.push_back(L);
+  }
+  p->n = n;
+  hipError_t e = psg::pool_alloc((void **)&p->d_levels, sizeof(MergeLevel) * (size_t)H);
+  if (e != hipSuccess) { psg_merge_plan_free(p); set_error("merge plan: hipMalloc failed"); return PSG_ENOMEM; }
+  if ((rc = psg::copy_h2d(p->d_levels, p->levels.data(), sizeof(MergeLevel) * (size_t)H))) { psg_merge_plan_free(p); return rc; }
+  *out = p;
+  return 0;
+}
+
+// =======================================================================================
 // K7 with the partial suffix arrays in host memory (psg_merge_stream)
 // =======================================================================================
 // cur[b * H + h] = number of own elements of half-block h among the first xs[b] output slots: the walk of

@@ -100,3 +100,57 @@ def test_english_like_with_host_sorter(gpu_lib):
     assert bad == 0 and s == (n * (n - 1) // 2) % (1 << 64)
     assert sum(p[3].unresolved for p in stats) >= 0
     print("english-like passes:", [(p[0], p[3].n_chains, p[3].warmup_steps, p[3].unresolved, p[3].rounds) for p in stats])
+
+
+WORKER_BLOCKS_GPU = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import orc
+import psascan_amd
+from psascan_amd import api, extras, blockdist as BD
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+psascan_amd.lib(0)                                   # every rank on the one GPU of this box (rehearsal)
+for mode, n in ((extras.MODE_BYTES255, 3_000_017), (extras.MODE_ENGLISH, 2_500_000), (extras.MODE_DNA, 1_999_999)):
+    d_text = extras.gen_text(n, mode, 0, seed=21)
+    ops = BD.HipBlockOps(torch, api, d_text, n, extras.DeviceSorter(d_text, n), comm="cpu", max_chains=4096)
+    stats = []
+    x0, x1, sa5 = BD.run(dist, ops, world, rank, n, stats)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(sa5)], dtype=torch.int64))
+    mx = max(int(s) for s in sizes)
+    buf = torch.zeros(mx, dtype=torch.uint8); buf[: len(sa5)] = torch.from_numpy(sa5)
+    parts = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    if rank == 0:
+        whole = np.concatenate([p.numpy()[: int(s)] for p, s in zip(parts, sizes)])
+        t = api.download(d_text, np.uint8, n)
+        assert np.array_equal(orc.sa5_to_sa(whole), orc.suffix_array(t)), mode
+    assert len(stats) == world - 1 - rank
+dist.barrier()
+dist.destroy_process_group()
+print("WORKER_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_per_gpu_schedule_real_kernels(gpu_lib, tmp_path, world):
+    """psascan_amd.blockdist with the real kernels: `world` processes share this box's one GPU and talk over gloo
+    (the same schedule runs over RCCL on a multi-GPU node).  Output compared with the oracle's suffix array."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_BLOCKS_GPU.format(root=root))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-3000:]
