@@ -19,7 +19,9 @@ the half-blocks is NOT part of the hot path (north_star keeps it on host cores);
 SAs on the device before the timed region.  `end_to_end_cli` times the whole construct_sa program on a bounded
 sample; `configs1_step` keeps last round's single-block step (4 GiB uniform bytes) as a secondary figure.
 
-N > 1: strong scaling of the configs[1] job with the tail-sharded pass (rank-log all-to-all), see config1().
+N > 1: north_star's multi-GPU split -- one 4 GiB block per GPU (text = N blocks), systolic rounds with ONE RCCL
+all-gather of the gt slices per round, output-range partitioned merge (psascan_amd/blockdist.py, config_blocks()).
+`--config 1` keeps last round's tail-sharded single-block job (rank-log all-to-all, config1()).
 
 Prints ONE JSON line (rank 0).
 """
@@ -84,7 +86,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=0, help="2 = configs[2] block schedule (default at 1 GPU), 1 = configs[1] single-block step (default at N > 1)")
+    ap.add_argument("--config", type=int, default=0, help="2 = configs[2] block schedule (default at 1 GPU), 3 = block-per-GPU schedule (default at N > 1), 1 = configs[1] single-block step (at N > 1: tail-sharded)")
     ap.add_argument("--gib", type=float, default=0.0, help="text size in GiB (default: 32 for configs[2], 4 for configs[1])")
     ap.add_argument("--block-gib", type=float, default=0.0, help="configs[2]: block size in GiB (default text/8)")
     ap.add_argument("--text", choices=["bytes", "dna", "english"], default=None, help="alphabet of the synthetic text (default: english for configs[2], bytes for configs[1])")
@@ -537,11 +539,87 @@ def config2(args, ctx, n, block):
     return res
 
 
+def config_blocks(args, ctx, block):
+    """N > 1: north_star's multi-GPU split (psascan_amd/blockdist.py) -- one block of `block` symbols per GPU, one
+    all-gather of the gt slices per round over RCCL, output-range partitioned merge.  Weak scaling in the data a GPU
+    holds (text = N blocks); the half-block suffix sorts are prepared on the device before the timed region."""
+    rank, world, local, dist, torch, np, api, extras, L, log = ctx
+    from psascan_amd import blockdist as BD
+    n = block * world
+    mode = {"bytes": extras.MODE_BYTES255, "dna": extras.MODE_DNA, "english": extras.MODE_ENGLISH}[args.text]
+    t0 = time.time()
+    d_text = extras.gen_text(n, mode, 0, seed=3)          # every rank holds the text (it streams the chunks of all blocks to its right)
+    bounds = BD.block_bounds(n, world)
+    b, e = bounds[rank], bounds[rank + 1]
+    mid = b + (e - b) // 2
+    prepared = {(hb, he): extras.sort_halfblock(d_text, n, hb, he) for hb, he in ((mid, e), (b, mid))}
+    api.sync()
+    log(f"rank 0 prepared its block of {n / 2 ** 30:.2f} GiB {args.text} text in {time.time() - t0:.1f}s")
+
+    def replay(text, hb, he, gt_tail):
+        r = prepared[(hb, he)]
+        return {"device": True, "psa_lo": r["psa_lo"], "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb}
+    comm = "cuda" if os.environ.get("PSASCAN_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+    ops = BD.HipBlockOps(torch, api, d_text, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True)
+    agg = {"suffixes": 0, "kernel_ms": 0.0, "stream_ms": 0.0, "launches": 0}
+
+    def step(timed):
+        stats = []
+        x0, x1, _ = BD.run(dist, ops, world, rank, n, stats)
+        if timed:
+            for (_, q, st) in stats:
+                agg["suffixes"] += bounds[q + 1] - bounds[q]; agg["kernel_ms"] += st.kernel_ms; agg["stream_ms"] += st.total_ms; agg["launches"] += st.rounds
+        return x0, x1
+
+    def barrier():
+        dist.barrier()
+        if comm == "cuda":
+            torch.cuda.synchronize()
+        api.sync()
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        x0, x1 = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=comm)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    bad, sm = extras.check_sa5(d_text, n, ops.d_out, x1 - x0, samples=1 << 18)
+    v = torch.tensor([bad, sm & 0x7FFFFFFFFFFFFFFF, sm >> 63, agg["suffixes"], int(agg["kernel_ms"] * 1000)], dtype=torch.int64, device=comm)
+    parts = [torch.empty_like(v) for _ in range(world)]
+    dist.all_gather(parts, v)
+    if rank != 0:
+        return None
+    bad = sum(int(p[0]) for p in parts)
+    sm = sum(int(p[1]) + (int(p[2]) << 63) for p in parts) % (1 << 64)
+    K = args.steps
+    suff = sum(int(p[3]) for p in parts) / K
+    kern0 = agg["kernel_ms"] / K / 1e3                       # rank 0 streams the most chunks: its kernel time bounds the rounds
+    suff0 = agg["suffixes"] / K
+    achieved = A_STREAM * suff0 / kern0 / 1e9 if kern0 else 0.0
+    return {
+        "metric": "input MB/s, hot path of the block-per-GPU schedule (local pass A + BWT merge + rank, systolic gap-stream rounds with one gt all-gather each, gap split, output-range partitioned merge)",
+        "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u40 integer", "data": "synthetic",
+        "config": {"workload": f"{n / 2 ** 30:.2f} GiB {args.text} text, {world} blocks of {block / 2 ** 30:.2f} GiB sharded one per GPU (BASELINE configs[3]'s split at configs[2]'s block size), "
+                               f"{world - 1} rounds, one RCCL all-gather of the gt slices per round, merge partitioned by output range",
+                   "text_bytes": n, "blocks": world, "block_bytes": block, "collectives_per_step": f"{world - 1} all-gathers of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts of {16 * (world + 1)} B, 1 all-to-all"},
+        "gap_stream_suffixes_per_s": suff / (elapsed / K), "streamed_suffixes_per_step": suff,
+        "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "traffic_source": "rank 0's launches; no PMC pass for the multi-GPU run", "algorithmic_bytes_per_suffix": A_STREAM,
+                     "suffixes_per_launch": suff0 / max(1, agg["launches"] / K), "avg_launch_ms": 1e3 * kern0 / max(1, agg["launches"] / K)},
+        "property_check": {"sampled_adjacent_pairs_out_of_order": bad, "sum_matches_permutation": sm == (n * (n - 1) // 2) % (1 << 64)},
+    }
+
+
 def main():
     args = parse()
     ctx = setup(args)
     rank, world, local, dist, torch, np, api, extras, L, log = ctx
-    cfg = args.config or (2 if world == 1 else 1)
+    cfg = args.config or (2 if world == 1 else 3)     # N > 1: the block-per-GPU schedule; --config 1: the tail-sharded single block
     if cfg == 2 and world == 1:
         args.text = args.text or "english"
         n = int((args.gib or 32.0) * (1 << 30)) // 4096 * 4096
@@ -564,6 +642,12 @@ def main():
             except Exception as e:
                 res["configs1_step"] = {"value": None, "note": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
+    elif world > 1 and cfg != 1:
+        args.text = args.text or "english"
+        block = int((args.block_gib or 4.0) * (1 << 30)) // 4096 * 4096
+        res = config_blocks(args, ctx, block)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
     else:
         args.text = args.text or "bytes"
         res = config1(args, ctx, args.gib or 4.0, args.steps, args.warmup, args.text, True)

@@ -172,9 +172,10 @@ class HipBlockOps:
     collectives are torch CUDA tensors (NCCL/RCCL; the library is put on torch's stream by the caller);
     comm = "cpu": CPU tensors (gloo; data is staged through the library's copies -- shared-GPU rehearsal)."""
 
-    def __init__(self, torch, api, d_text, n, sorter, comm="cuda", max_chains=0, host_text=None):
+    def __init__(self, torch, api, d_text, n, sorter, comm="cuda", max_chains=0, keep_output_on_device=False):
         self.torch, self.api, self.d_text, self.n, self.sorter, self.comm, self.max_chains = torch, api, d_text, n, sorter, comm, max_chains
-        self.host_text = host_text
+        self.keep_output_on_device = keep_output_on_device
+        self.d_out = None
 
     # ---- tensors
     def new_i32(self, k):
@@ -213,6 +214,15 @@ class HipBlockOps:
         a = self.api.download(buf_or_ptr, np.int32, nwords)
         return self.torch.from_numpy(a).to(self.comm)
 
+    def _slice_out(self, words):
+        """(tensor, device pointer, finish()) of a zeroed gt slice the kernels write: with comm = "cuda" the tensor IS
+        the device buffer (no copy); with comm = "cpu" a device buffer that finish() downloads into the tensor"""
+        if self.comm == "cuda":
+            t = self.new_i32(words)
+            return t, t.data_ptr(), (lambda: t)
+        buf = self.api.zeros(4 * words)
+        return None, buf.ptr, (lambda: self._from_dev(buf, words))
+
     def sym(self, pos):
         return int(self.api.download(self.d_text, np.uint8, 1, pos)[0])
 
@@ -239,10 +249,11 @@ class HipBlockOps:
         st.bvA = api.zeros(4 * ((bs + 31) // 32 + 2))
         assert api.gap_to_bitvector(gapA, ls, st.bvA, bs) == bs
         gapA.free()
-        own = api.zeros(4 * words)
+        _, own, done = self._slice_out(words)
         api.bitcopy(own, 0, gtA, 0, rs)                       # positions (mid, e]: u = e - j
         api.bitcopy(own, rs, L["gt_begin"], 0, ls)            # positions (b, mid]
-        st.own_gt = self._from_dev(own, words)
+        api.sync()
+        st.own_gt = done()
         st.rank = None
         if e < n:                                             # not the last block: it will be streamed through
             d_bbwt = api.DeviceBuffer(bs + 16)
@@ -260,10 +271,10 @@ class HipBlockOps:
         api = self.api
         T = ce - cb
         keep, gin = self._to_dev(gt_in_t, (T + 31) // 32 + 1)
-        gout = api.zeros(4 * words)
+        _, gout, done = self._slice_out(words)
         _, s = api.stream_gap(st.rank, st.block_i0, st.last, self.d_text.at(cb), T, gin, start_rank, st.gap, gout, self.max_chains, fresh_gap=first)
         st.last_stats = s
-        return self._from_dev(gout, words)
+        return done()
 
     def finish(self, st, T):
         api = self.api
@@ -307,4 +318,6 @@ class HipBlockOps:
         plan.run(x0, x1 - x0, d_out)
         plan.free()
         self.d_out = d_out
+        if self.keep_output_on_device:
+            return None
         return api.download(d_out, np.uint8, 5 * (x1 - x0))
