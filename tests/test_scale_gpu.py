@@ -154,3 +154,45 @@ def test_block_per_gpu_schedule_real_kernels(gpu_lib, tmp_path, world):
             p.kill()
             o, _ = p.communicate()
         assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-3000:]
+
+
+def test_configs1_full_size_properties(gpu_lib):
+    """BASELINE configs[1] at full size, as a test: 4 GiB of uniform bytes, one block of two 2 GiB half-blocks --
+    rank build (LIST8 symbol-major), pass A over 2^31 suffixes (rank log + two-level partition + window histograms,
+    fresh gap array), gap -> bitvector, two-way merge to 4 Gi uint40 entries.  Size-independent properties: the
+    library's own invariants (sum(gap) == tail length, chain hand-over ranks), the output is a permutation and 2^20
+    sampled adjacent entries are in suffix order."""
+    from psascan_amd import api, extras
+    n = 4 << 30
+    mid = n // 2
+    d_text = extras.gen_text(n, extras.MODE_BYTES255, 0, seed=2)
+    Rh = extras.sort_halfblock(d_text, n, mid, n)
+    Lh = extras.sort_halfblock(d_text, n, 0, mid)
+    last_left = int(api.download(d_text, np.uint8, 1, mid - 1)[0])
+    rk = api.rank_build(Lh["bwt"], mid)
+    gap = api.gap_array(mid, fill=None)
+    gt_out = api.zeros(4 * ((n - mid + 31) // 32 + 4))
+    fin, st = api.stream_gap(rk, Lh["i0"], last_left, d_text.at(mid), n - mid, Rh["gt_begin"], 0, gap, gt_out, 0, fresh_gap=True)
+    assert st.hist_ms > 0 and st.rounds == 1 and st.unresolved == 0
+    rk.free()
+    mbv = api.zeros(4 * ((n + 31) // 32 + 2))
+    assert api.gap_to_bitvector(gap, mid, mbv, n) == n
+    assert api.popcount(mbv, n) == n - mid
+    Lh["mbv"] = mbv
+    d_out = api.merge_half_blocks([Lh, Rh])
+    bad, s = extras.check_sa5(d_text, n, d_out, n, samples=1 << 20, seed=3)
+    assert bad == 0 and s == (n * (n - 1) // 2) % (1 << 64)
+
+
+def test_bench_configs2_shape_reduced(gpu_lib):
+    """bench.py's configs[2] step at a reduced size (4 GiB English-like text, 8 blocks = 16 half-blocks, partial SAs
+    in pinned host memory, streamed merge): the step verifies its own output on the device and raises otherwise."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gib", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
+                        "--with-output-d2h"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["blocks"] == 8 and d["config"]["half_blocks"] == 16 and d["value"] > 0
+    assert d["pcie"]["h2d_bytes_per_step"] == 4 * (4 << 30) and d["with_output_d2h"]["entries_received_on_host"] == 4 << 30
+    assert d["roofline"]["frac"] > 0.05 and d["streamed_suffixes_per_step"] > 15 * (1 << 30)
