@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--block-gib", type=float, default=0.0, help="configs[2]: block size in GiB (default text/8)")
     ap.add_argument("--text", choices=["bytes", "dna", "english"], default=None, help="alphabet of the synthetic text (default: english for configs[2], bytes for configs[1])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] secondary figure and the CLI sample")
+    ap.add_argument("--psa-hbm-gib", type=float, default=-1.0, help="configs[2]: GiB of partial SAs kept resident in HBM next to the pass temporaries (default: as many half-blocks as fit, sized by an untimed step)")
     ap.add_argument("--with-output-d2h", action="store_true", help="configs[2]: also time one step with the .sa5 slices copied back to the host")
     ap.add_argument("--max-chains", type=int, default=0)
     ap.add_argument("--rank-block", type=int, default=0, help="data bytes per rank block (0=auto)")
@@ -434,7 +435,7 @@ def config2(args, ctx, n, block):
             r["psa_lo"].free()
             tpin += time.time() - t1
             pins.append(pa)
-            prepared[(hb, he)] = {"device": True, "psa_host": pa.array, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
+            prepared[(hb, he)] = {"device": True, "psa_host": pa.array, "psa_lo": None, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
                                   "initA": init, "keep_inputs": True}
     L.psg_trim()        # the sorter's temporaries go back to the driver: the step starts from the resident inputs only
     log(f"prepared {n / 2 ** 30:.2f} GiB {args.text} text, {len(prepared)} half-blocks in {time.time() - t0:.1f}s (device sort {tsort:.1f}s, pinned alloc + D2H {tpin:.1f}s)")
@@ -472,7 +473,28 @@ def config2(args, ctx, n, block):
         last["stats"], last["ms"] = stats, ms
         return te - ts
 
-    for _ in range(args.warmup):
+    # ---- partial SAs that fit in HBM next to the pass temporaries are resident inputs (no PCIe for them); the first
+    # untimed step measures the peak of everything else
+    warm = args.warmup
+    resident = 0
+    if args.psa_hbm_gib != 0:
+        step(False)
+        warm = max(0, warm - 1)
+        _, peak0, _ = api.mem_stats()
+        total = api.device_memory()[1]
+        budget = int(args.psa_hbm_gib * 2 ** 30) if args.psa_hbm_gib > 0 else total - peak0 - (20 << 30)
+        L.psg_trim()
+        for key in sorted(prepared, key=lambda k: -k[0]):           # rightmost half-blocks first
+            v = prepared[key]
+            if 4 * v["size"] + (1 << 20) > budget:
+                continue
+            d = api.DeviceBuffer(4 * v["size"] + 16)
+            api.check(L.psg_h2d(d.ptr, v["psa_host"].ctypes.data, 4 * v["size"]))
+            v["psa_lo"], v["psa_host"] = d, None
+            budget -= 4 * v["size"] + (1 << 20)
+            resident += 1
+        log(f"{resident} of {len(prepared)} partial SAs resident in HBM ({sum(4 * v['size'] for v in prepared.values() if v['psa_host'] is None) / 2 ** 30:.1f} GiB), the rest in pinned host memory")
+    for _ in range(warm):
         step(False)
     api.sync()
     t_start = time.perf_counter()
@@ -508,7 +530,8 @@ def config2(args, ctx, n, block):
         "config": {"workload": f"configs[2]: {n / 2 ** 30:.2f} GiB {'English-like text (seeded Zipfian words, sigma=28)' if args.text == 'english' else args.text + ' text'}, "
                                f"{len(plan)} blocks of {block / 2 ** 30:.2f} GiB = {len(prepared)} half-blocks on 1 GPU, whole schedule (passes A and B of every block + final merge)",
                    "text_bytes": n, "blocks": len(plan), "half_blocks": len(prepared), "block_bytes": block,
-                   "resident_in_hbm": "text, BWT + gt bits of every half-block, merge bitvectors", "in_pinned_host_memory": "partial suffix arrays (4 B/symbol), streamed during the merge",
+                   "resident_in_hbm": f"text, BWT + gt bits of every half-block, merge bitvectors, {resident} of {len(prepared)} partial suffix arrays",
+                   "in_pinned_host_memory": f"{len(prepared) - resident} of {len(prepared)} partial suffix arrays (4 B/symbol), streamed during the merge",
                    "rank_bytes_per_symbol_pass_B": round(sum(rankB) / max(1, len(rankB)), 3)},
         "gap_stream_suffixes_per_s": suff / (agg["stream_ms"] / K / 1e3),
         "gap_stream_kernel_suffixes_per_s": suff / kern_s if kern_s else None,
@@ -534,6 +557,8 @@ def config2(args, ctx, n, block):
         pa.free()
     for v in prepared.values():
         v["bwt"].free(); v["gt_begin"].free()
+        if v.get("psa_lo") is not None:
+            v["psa_lo"].free()
     d_text.free()
     L.psg_trim()
     return res

@@ -472,7 +472,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   std::vector<psg_hb_host_desc> desc(hbs.size());
   for (size_t h = 0; h < hbs.size(); ++h) {
     hbs[h].map_back();
-    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr};
+    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr, nullptr, nullptr};
   }
   struct SinkCtx { FILE *out; bool ok; int64_t entries; } sctx{out, true, 0};
   psg_sink_fn sink = [](void *c, const uint8_t *h_sa5, int64_t, int64_t cnt) -> int {

@@ -56,6 +56,8 @@ int psg_host_alloc(void **h_ptr, int64_t bytes);
 int psg_host_free(void *h_ptr);
 /* device memory: bytes handed out by psg_malloc right now / the highest value so far / held from the driver */
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved);
+/* the device's memory as the driver sees it (hipMemGetInfo) */
+int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes);
 /* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int psg_set_stream(void *hip_stream);
 
@@ -244,6 +246,8 @@ typedef struct {
   const uint32_t *h_psa_lo;
   const uint8_t *h_psa_hi;   /* may be NULL */
   const uint32_t *d_mbv;     /* device; size + (sizes of all later half-blocks) bits; NULL for the last */
+  const uint32_t *d_psa_lo;  /* optional: this half-block's partial SA is ALREADY in HBM (h_psa_* are then ignored): */
+  const uint8_t *d_psa_hi;   /* a caller with HBM to spare keeps some of them resident and saves their PCIe transfer */
 } psg_hb_host_desc;
 typedef int (*psg_sink_fn)(void *ctx, const uint8_t *h_sa5, int64_t first_entry, int64_t n_entries);
 typedef struct {

@@ -22,7 +22,8 @@ class HbDescC(C.Structure):
 
 
 class HbHostDescC(C.Structure):
-    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("h_psa_lo", C.c_void_p), ("h_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p)]
+    _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("h_psa_lo", C.c_void_p), ("h_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p),
+                ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p)]
 
 
 class MergeCheckC(C.Structure):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "psg_host_alloc": (_int, [C.POINTER(_vp), _i64]),
     "psg_host_free": (_int, [_vp]),
     "psg_mem_stats": (_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "psg_device_memory": (_int, [C.POINTER(_i64), C.POINTER(_i64)]),
     "psg_set_stream": (_int, [_vp]),
     "psg_gap_words": (_i64, [_i64]),
     "psg_gap_values": (_int, [_vp, _i64, _vp]),

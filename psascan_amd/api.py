@@ -340,6 +340,13 @@ def mem_stats():
     return a.value, b.value, c.value
 
 
+def device_memory():
+    """(free, total) bytes of the device as the driver sees it"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    check(lib().psg_device_memory(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, samples_per_slice=0, seed=1):
     """merge<T> with the partial SAs in host memory (numpy arrays / PinnedArray.array under "psa_lo", optional
     "psa_hi"), merge bitvectors on the device.  sink(bytes_view: np.uint8, first_entry, n_entries) is called in
@@ -348,16 +355,20 @@ def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, sa
     arr = (HbHostDescC * H)()
     keep = []
     for k, hb in enumerate(half_blocks):
+        arr[k].beg, arr[k].size = hb["beg"], hb["size"]
+        arr[k].d_mbv = _ptr(hb.get("mbv"))
+        if isinstance(hb["psa_lo"], DeviceBuffer):          # resident in HBM: used where it lies
+            arr[k].d_psa_lo = hb["psa_lo"].ptr
+            arr[k].d_psa_hi = _ptr(hb.get("psa_hi"))
+            continue
         lo = np.ascontiguousarray(hb["psa_lo"], np.uint32) if not isinstance(hb["psa_lo"], np.ndarray) or hb["psa_lo"].dtype != np.uint32 else hb["psa_lo"]
         keep.append(lo)
-        arr[k].beg, arr[k].size = hb["beg"], hb["size"]
         arr[k].h_psa_lo = lo.ctypes.data
         hi = hb.get("psa_hi")
         if hi is not None:
             hi = np.ascontiguousarray(hi, np.uint8)
             keep.append(hi)
             arr[k].h_psa_hi = hi.ctypes.data
-        arr[k].d_mbv = _ptr(hb.get("mbv"))
     err = []
 
     def _sink(ctx, ptr, first, cnt):

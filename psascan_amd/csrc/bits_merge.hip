@@ -955,9 +955,9 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   std::vector<psg_hb_desc> dd((size_t)H);
   bool any_hi = false;
   for (int h = 0; h < H; ++h) {
-    PSG_REQUIRE(hbs[h].h_psa_lo, "psg_merge_stream: partial suffix array missing");
+    PSG_REQUIRE(hbs[h].h_psa_lo || hbs[h].d_psa_lo, "psg_merge_stream: partial suffix array missing");
     dd[(size_t)h] = psg_hb_desc{hbs[h].beg, hbs[h].size, nullptr, nullptr, hbs[h].d_mbv};
-    any_hi |= hbs[h].h_psa_hi != nullptr;
+    any_hi |= hbs[h].d_psa_lo ? hbs[h].d_psa_hi != nullptr : hbs[h].h_psa_hi != nullptr;
   }
   psg_merge_plan *plan = nullptr;
   if (int rc = plan_build(dd.data(), H, false, &plan)) return rc;
@@ -984,7 +984,11 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   DevBuf din[2], dout[2], dlv[2], acc;
   char *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
   MergeLevel *pin_lv[2] = {nullptr, nullptr};
-  const bool direct = [&] { for (int h = 0; h < H; ++h) if (!host_ptr_is_pinned(hbs[h].h_psa_lo) || (hbs[h].h_psa_hi && !host_ptr_is_pinned(hbs[h].h_psa_hi))) return false; return true; }();
+  const bool direct = [&] {
+    for (int h = 0; h < H; ++h)
+      if (!hbs[h].d_psa_lo && (!host_ptr_is_pinned(hbs[h].h_psa_lo) || (hbs[h].h_psa_hi && !host_ptr_is_pinned(hbs[h].h_psa_hi)))) return false;
+    return true;
+  }();
   for (int s = 0; s < 2; ++s) {
     if ((rc = din[s].alloc(in_cap)) || (rc = dout[s].alloc(out_cap)) || (rc = dlv[s].alloc((i64)sizeof(MergeLevel) * H))) return rc;
     if (!direct) pin_in[s] = (char *)pinned_buf(8 + s, (size_t)in_cap);
@@ -1027,6 +1031,20 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
     for (int h = 0; h < H; ++h) {
       const i64 c0 = cur[(size_t)k * H + h], c1 = cur[(size_t)(k + 1) * H + h], len = c1 - c0;
       MergeLevel L = plan->levels[(size_t)h];
+      if (hbs[h].d_psa_lo) {                                       // resident in HBM: used where it lies
+        L.lo = hbs[h].d_psa_lo;
+        L.hi = hbs[h].d_psa_hi;
+        if (any_hi && !L.hi) {                                     // the kernel variant with high bytes reads them for every level
+          L.hi = (const u8 *)(din[s].as<char>() + offh) - c0;
+          if (len > 0) {
+            if (direct) PSG_HIP(hipMemsetAsync(din[s].as<char>() + offh, 0, (size_t)len, up));
+            else memset(pin_in[s] + offh, 0, (size_t)len);
+          }
+          offh += (len + 15) / 16 * 16;
+        }
+        pin_lv[s][h] = L;
+        continue;
+      }
       L.lo = (const u32 *)(din[s].as<char>() + off) - c0;          // absolute indices c0.. land inside the piece
       L.hi = nullptr;
       if (len > 0) {

@@ -460,6 +460,13 @@ int psg_host_free(void *h_ptr) {
   PSG_HIP(hipHostFree(h_ptr));
   return 0;
 }
+int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
+  size_t f = 0, t = 0;
+  PSG_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return 0;
+}
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   size_t res = g_small_reserved;

@@ -112,7 +112,7 @@ def construct_sa5(text, max_block_size, ram_use, sorter, max_chains=0, stats=Non
     def up_hb(beg, res):
         if res.get("psa_host") is not None:
             return {"beg": beg, "size": res["size"], "psa_lo": res["psa_host"], "psa_hi": None, "mbv": None, "dev_psa": None}
-        if res.get("device"):
+        if res.get("device"):        # resident in HBM (the streamed merge uses it where it lies)
             return {"beg": beg, "size": res["size"], "psa_lo": res["psa_lo"], "psa_hi": None, "mbv": None, "dev_psa": res["psa_lo"]}
         psa = np.asarray(res["psa"], np.uint64)
         if merge == "stream":
