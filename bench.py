@@ -482,13 +482,16 @@ def config2(args, ctx, n, block):
         warm = max(0, warm - 1)
         _, peak0, _ = api.mem_stats()
         total = api.device_memory()[1]
-        budget = int(args.psa_hbm_gib * 2 ** 30) if args.psa_hbm_gib > 0 else total - peak0 - (20 << 30)
+        budget = int(args.psa_hbm_gib * 2 ** 30) if args.psa_hbm_gib > 0 else total - peak0 - (36 << 30)   # headroom: arena granules, fragmentation
         L.psg_trim()
         for key in sorted(prepared, key=lambda k: -k[0]):           # rightmost half-blocks first
             v = prepared[key]
             if 4 * v["size"] + (1 << 20) > budget:
                 continue
-            d = api.DeviceBuffer(4 * v["size"] + 16)
+            try:
+                d = api.DeviceBuffer(4 * v["size"] + 16)
+            except Exception:
+                break                                               # no room after all: the rest stays in host memory
             api.check(L.psg_h2d(d.ptr, v["psa_host"].ctypes.data, 4 * v["size"]))
             v["psa_lo"], v["psa_host"] = d, None
             budget -= 4 * v["size"] + (1 << 20)

@@ -7,6 +7,15 @@
 //                --check[=N]      verify the output on the device while it is merged (permutation sum + N sampled
 //                                 adjacent pairs per slice in suffix order); failure = exit status 1
 //                --discard-output produce the .sa5 bytes (they reach host memory) but write no file
+//                --leaf-size N / --fanout F / --no-device-merge
+//                                 half-blocks are suffix-sorted as leaves of <= N symbols on the host cores (2 MiB:
+//                                 the sort stays in the caches) and merged on the device, F sub-ranges at a time --
+//                                 the in-memory pSAscan of the reference (inmem_psascan.hpp:64-304) with the GPU as
+//                                 the merger
+//                --device-sort    NOT the reference's placement (north_star keeps the half-block suffix sort on host
+//                                 cores, and that is the default): sort the half-blocks on the device with the
+//                                 bench's prefix-key sorter (psascan_amd_extras.h; texts whose repeats stay below a
+//                                 few hundred symbols -- anything else falls back to the host sorter)
 //                --spill-psa      keep the partial suffix arrays in part files next to GAPFILE (-g; default: the
 //                                 output name) instead of host memory: `GAPFILE.psa.<beg>` is written when a block
 //                                 is done and mapped back for the merge (the reference's distributed_file,
@@ -37,12 +46,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../include/psascan_amd.h"
+#include "../include/psascan_amd_extras.h"
 #include "halfblock.hpp"
 
 using psa_host::HalfBlock;
@@ -71,7 +82,13 @@ static void usage(int status) {
          "                          4096) sampled adjacent pairs per slice in suffix order (extension)\n"
          "      --discard-output    do everything but write the output file (extension)\n"
          "      --spill-psa         partial suffix arrays in part files GAPFILE.psa.* instead of host\n"
-         "                          memory (extension)\n",
+         "                          memory (extension)\n"
+         "      --leaf-size=N       half-blocks larger than N (default 2Mi) are cut into leaves of at most N\n"
+         "                          symbols that are suffix-sorted on the host and merged on the device\n"
+         "      --fanout=F          sub-ranges merged per step of that merging (default 4)\n"
+         "      --no-device-merge   sort every half-block in one piece on the host (extension)\n"
+         "      --device-sort       suffix-sort the half-blocks on the device (extension; the default keeps\n"
+         "                          the sort on the host cores like the reference)\n",
          program_name);
   std::exit(status);
 }
@@ -190,7 +207,12 @@ static void log_phase(const char *what, double t0, int64_t units = 0) {
   else fprintf(stderr, "    %s: %.2fs\n", what, dt);
 }
 
-struct Options { int64_t forced_block = 0, max_chains = 0, check_samples = -1; bool discard = false, spill_psa = false; std::string gap_prefix; };
+struct Options {
+  int64_t forced_block = 0, max_chains = 0, check_samples = -1, leaf_size = 0;
+  int fanout = 4;
+  bool discard = false, spill_psa = false, hierarchical = true, device_sort = false;
+  std::string gap_prefix;
+};
 
 static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt) {
   const int64_t forced_block = opt.forced_block, max_chains = opt.max_chains;
@@ -231,14 +253,6 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   std::vector<DoneHalfBlock> hbs;
   std::vector<uint32_t> cur_host;
 
-  auto keep_hb = [&](HalfBlock &h) {   // the partial SA stays on the host; everything else of the half-block is dropped
-    DoneHalfBlock d;
-    d.beg = h.beg; d.size = h.size;
-    d.psa_lo.swap(h.psa_lo); d.psa_hi.swap(h.psa_hi);
-    std::vector<uint8_t>().swap(h.bwt);
-    std::vector<uint32_t>().swap(h.gt_begin);
-    return d;
-  };
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
 
@@ -273,68 +287,85 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (rc) throw std::runtime_error(std::string("psg_stream_gap_args: ") + psg_last_error());
   };
 
-  // ---- look-ahead sorter: all half-blocks on all host cores, right to left (the order the schedule needs them).
-  // The comparisons that run past a half-block's end are decided by reading on in the text, which is in host
-  // memory, instead of by the gt bits of the blocks to the right (initial_partial_sufsort.hpp:61-80) -- so a
-  // half-block depends on nothing.  A half-block whose comparisons run longer than LOOKAHEAD_CAP symbols is
-  // left to the sequential schedule below (gt bits from the streaming passes, as in the reference).
+  // ---- look-ahead sorter: LEAVES on all host cores, right to left (the order the schedule needs them).
+  // A half-block larger than the leaf size is cut into leaves that ARE suffix-sorted on the host; their partial
+  // SAs are merged on the device with the hot path itself -- the reference's in-memory pSAscan does the same with
+  // max_threads sub-blocks per block (inmem_psascan.hpp:64-304).  Small leaves stay inside the host caches (2 MiB
+  // leaves sort at ~50 MB/s per core, 1 GiB half-blocks at ~7), and the merging is what the GPU is fast at.
+  // Comparisons that run past a leaf's end are decided by reading on in the text, which is in host memory, instead
+  // of by gt bits of what lies to the right (initial_partial_sufsort.hpp:61-80) -- so a leaf depends on nothing.  A
+  // leaf whose comparisons run longer than LOOKAHEAD_CAP symbols (periodic text) fails; its half-block is then sorted
+  // in one piece in the sequential schedule, with gt bits from the streaming passes, as in the reference.
   const int64_t LOOKAHEAD_CAP = 1 << 16;
-  struct Pre { std::unique_ptr<HalfBlock> hb; bool done = false, failed = false; double seconds = 0; };
-  std::vector<Pre> pre((size_t)(2 * n_blocks));           // [2*bid] = left half, [2*bid+1] = right half
-  std::mutex pre_mu;
-  std::condition_variable pre_cv;
-  std::atomic<int64_t> next_task{0};
-  std::vector<int64_t> task_order;                        // right half of the last block first
-  for (int64_t bid = n_blocks - 1; bid >= 0; --bid) { task_order.push_back(2 * bid + 1); task_order.push_back(2 * bid); }
+  const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD") && !opt.device_sort;
+  const int64_t leaf_size = opt.leaf_size > 0 ? opt.leaf_size : ((int64_t)2 << 20);
+  struct Task { int64_t beg, end; };
+  std::vector<Task> tasks;                                   // in the order the schedule consumes them
+  std::vector<std::vector<int64_t>> half_tasks((size_t)(2 * n_blocks));   // half id -> its task ids, LEFT to RIGHT
   auto half_range = [&](int64_t id, int64_t &hb_beg, int64_t &hb_end) {
     const int64_t bid = id / 2, b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
     const bool last = e == n;
     const int64_t ls = last ? std::min<int64_t>(bs, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, bs / 2);
     if (id & 1) { hb_beg = b + ls; hb_end = e; } else { hb_beg = b; hb_end = b + ls; }
   };
-  const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD");
-  // how far the sorters may run ahead of the schedule: a finished half-block holds ~5 bytes per symbol until it
-  // is consumed and a running sort ~25 more, so the window is bounded by a quarter of the physical memory
-  int64_t consumed = 0;            // tasks (in task_order) the schedule has taken; guarded by pre_mu
+  for (int64_t bid = n_blocks - 1; bid >= 0; --bid)
+    for (int side = 1; side >= 0; --side) {                  // right half first
+      int64_t hb, he;
+      half_range(2 * bid + side, hb, he);
+      if (he <= hb) continue;
+      const int64_t nleaves = lookahead && opt.hierarchical ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
+      std::vector<int64_t> ids;
+      for (int64_t k = nleaves - 1; k >= 0; --k) {           // rightmost leaf first
+        const int64_t lb = hb + (he - hb) * k / nleaves, le = hb + (he - hb) * (k + 1) / nleaves;
+        ids.push_back((int64_t)tasks.size());
+        tasks.push_back(Task{lb, le});
+      }
+      std::reverse(ids.begin(), ids.end());
+      half_tasks[(size_t)(2 * bid + side)] = ids;
+    }
+  struct Pre { std::unique_ptr<HalfBlock> hb; bool done = false, failed = false; };
+  std::vector<Pre> pre(tasks.size());
+  std::mutex pre_mu;
+  std::condition_variable pre_cv;
+  std::atomic<int64_t> next_task{0};
+  // how far the sorters may run ahead of the schedule: a finished leaf holds ~5 bytes per symbol until it is
+  // consumed and a running sort ~25 more, so the window is bounded by a quarter of the physical memory
+  int64_t consumed = 0;            // tasks the schedule has taken; guarded by pre_mu
   bool stop_workers = false;       // set when the schedule ends (normally or by an exception); guarded by pre_mu
   int64_t window = 2;
   {
-    const int64_t half_bytes = std::max<int64_t>(1, (max_block_size + 1) / 2);
+    int64_t task_bytes = 1;
+    for (const Task &t : tasks) task_bytes = std::max(task_bytes, t.end - t.beg);
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
     const int64_t phys = pages > 0 && psz > 0 ? (int64_t)pages * psz : ((int64_t)16 << 30);
-    window = std::max<int64_t>(2, std::min<int64_t>(4 * max_threads, (phys / 4) / (30 * half_bytes)));
+    window = std::max<int64_t>(2 * max_threads, std::min<int64_t>((int64_t)1 << 16, (phys / 4) / (30 * task_bytes)));
   }
   std::vector<std::thread> workers;
   if (lookahead) {
-    const long nthreads = std::min<long>(max_threads, (long)task_order.size());
+    const long nthreads = std::min<long>(max_threads, (long)tasks.size());
     for (long t = 0; t < nthreads; ++t)
       workers.emplace_back([&]() {
         for (;;) {
           const int64_t k = next_task.fetch_add(1);
-          if (k >= (int64_t)task_order.size()) return;
+          if (k >= (int64_t)tasks.size()) return;
           {
             std::unique_lock<std::mutex> lk(pre_mu);
             pre_cv.wait(lk, [&] { return stop_workers || k < consumed + window; });
             if (stop_workers) return;
           }
-          const int64_t id = task_order[(size_t)k];
-          int64_t hb_beg, hb_end;
-          half_range(id, hb_beg, hb_end);
+          const int64_t hb_beg = tasks[(size_t)k].beg, hb_end = tasks[(size_t)k].end;
           std::unique_ptr<HalfBlock> h;
           bool failed = false;
-          const double t0 = wclock();
-          if (hb_end > hb_beg) {
-            try {
+          try {
+            h.reset(new HalfBlock());
+            if (!psa_host::sort_halfblock_radix(text.data(), n, hb_beg, hb_end, *h, LOOKAHEAD_CAP)) {   // text with repeats: SA-IS
               h.reset(new HalfBlock());
-              if (!psa_host::sort_halfblock_radix(text.data(), n, hb_beg, hb_end, *h, LOOKAHEAD_CAP)) {   // text with repeats: SA-IS
-                h.reset(new HalfBlock());
-                psa_host::sort_halfblock(text.data(), n, hb_beg, hb_end, psa_host::gt_tail_direct(text.data(), n, hb_end, LOOKAHEAD_CAP), *h, LOOKAHEAD_CAP);
-              }
-            } catch (const psa_host::GtCapExceeded &) { h.reset(); failed = true; }
-              catch (...) { h.reset(); failed = true; }       // e.g. byte 255: reported by the sequential path
-          }
+              psa_host::sort_halfblock(text.data(), n, hb_beg, hb_end, psa_host::gt_tail_direct(text.data(), n, hb_end, LOOKAHEAD_CAP), *h, LOOKAHEAD_CAP);
+            }
+          } catch (const psa_host::GtCapExceeded &) { h.reset(); failed = true; }
+            catch (...) { h.reset(); failed = true; }       // e.g. byte 255: reported by the sequential path
           std::lock_guard<std::mutex> lk(pre_mu);
-          pre[(size_t)id].hb = std::move(h); pre[(size_t)id].failed = failed; pre[(size_t)id].seconds = wclock() - t0; pre[(size_t)id].done = true;
+          pre[(size_t)k].hb = std::move(h); pre[(size_t)k].failed = failed; pre[(size_t)k].done = true;
           pre_cv.notify_all();
         }
       });
@@ -347,14 +378,154 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       for (auto &t : w) if (t.joinable()) t.join();
     }
   } joiner{workers, pre_mu, pre_cv, stop_workers};
-  // the pre-sorted half-block `id`, or null when there is none (look-ahead off, or it gave up)
-  auto take_pre = [&](int64_t id) -> std::unique_ptr<HalfBlock> {
-    if (!lookahead) return nullptr;
+  // the pre-sorted leaves of half `id`, left to right; empty when there are none (look-ahead off) or one gave up
+  auto take_leaves = [&](int64_t id) -> std::vector<std::unique_ptr<HalfBlock>> {
+    std::vector<std::unique_ptr<HalfBlock>> out;
+    if (!lookahead) return out;
+    const std::vector<int64_t> &ids = half_tasks[(size_t)id];
     std::unique_lock<std::mutex> lk(pre_mu);
-    pre_cv.wait(lk, [&] { return pre[(size_t)id].done; });
-    ++consumed;                      // the tasks are taken in task_order, one per call
+    pre_cv.wait(lk, [&] { for (int64_t k : ids) if (!pre[(size_t)k].done) return false; return true; });
+    consumed += (int64_t)ids.size();                       // the tasks are taken in order, one half at a time
     pre_cv.notify_all();
-    return std::move(pre[(size_t)id].hb);
+    bool ok = true;
+    for (int64_t k : ids) ok = ok && pre[(size_t)k].hb != nullptr;
+    for (int64_t k : ids) { if (ok) out.push_back(std::move(pre[(size_t)k].hb)); else pre[(size_t)k].hb.reset(); }
+    return out;
+  };
+
+  // ---- in-HBM merge of sorted sub-ranges into the partial SA of their union (inmem_psascan.hpp:233-304): the block
+  // schedule in small -- sub-range i streams the sub-ranges to its right through its rank structure, the gap array
+  // becomes its merge bitvector, one merge yields the union's partial SA; BWT, i0 and gt_begin follow from it.
+  struct DevNode { int64_t beg = 0, size = 0, i0 = 0; Dev psa, bwt, gt; };
+  int64_t inner_passes = 0, inner_suffixes = 0;
+  psg_search_ctx sc_text{};                                  // comparisons by reading on in the text (cmp_end = n)
+  sc_text.d_text = d_text.as<uint8_t>(); sc_text.n = n; sc_text.cmp_end = n; sc_text.d_gt_cmp_end = nullptr; sc_text.nparts = 0;
+  auto upload_leaf = [&](HalfBlock &h) {
+    DevNode d;
+    d.beg = h.beg; d.size = h.size; d.i0 = h.i0;
+    d.psa = upload(h.psa_lo.data(), 4 * h.size);
+    d.bwt = upload(h.bwt.data(), h.size);
+    d.gt = upload(h.gt_begin.data(), 4 * (int64_t)h.gt_begin.size());
+    return d;
+  };
+  auto merge_nodes = [&](std::vector<DevNode> &ch) -> DevNode {
+    const int f = (int)ch.size();
+    const int64_t b = ch[0].beg, e = ch[(size_t)f - 1].beg + ch[(size_t)f - 1].size, R = e - b;
+    const int64_t gtw = (R + 31) / 32 + 4;
+    Dev gt_c(4 * gtw, true), gt_n(4 * gtw, true);            // bit u <-> position e - u, w.r.t. the begin of the sub-range being processed
+    std::vector<Dev> mbv((size_t)f);
+    CK(psg_bitcopy(gt_c.as<uint32_t>(), 0, ch[(size_t)f - 1].gt.as<uint32_t>(), 0, ch[(size_t)f - 1].size));
+    for (int i = f - 2; i >= 0; --i) {
+      DevNode &c = ch[(size_t)i];
+      const int64_t x1 = c.beg + c.size, T = e - x1;
+      psg_search_ctx sc = sc_text;
+      sc.nparts = 1; sc.part[0].beg = c.beg; sc.part[0].size = c.size; sc.part[0].d_psa_lo = c.psa.as<uint32_t>(); sc.part[0].d_psa_hi = nullptr;
+      int64_t r_end = 0;
+      if (e < n) CK(psg_initial_ranks(&sc, &e, 1, &r_end));
+      psg_rank_t *rk = nullptr;
+      CK(psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk));
+      Dev gap(4 * psg_gap_words(c.size), false);
+      CK(psg_memset(gt_n.p, 0, gt_n.bytes));
+      psg_stream_args a{};
+      a.rank = rk; a.block_i0 = c.i0; a.block_last_symbol = text.p[(size_t)x1 - 1]; a.d_tail = d_text.as<uint8_t>() + x1; a.tail_len = T; a.right_context = 0;
+      a.d_gt_in = gt_c.as<uint32_t>(); a.rank_at_context_end = r_end; a.d_gap = gap.as<uint32_t>(); a.d_gt_out = gt_n.as<uint32_t>(); a.max_chains = max_chains;
+      a.flags = PSG_GAP_UNINITIALIZED; a.search = &sc; a.tail_begin_abs = x1;
+      psg_stream_stats st;
+      if (psg_stream_gap_args(&a, nullptr, &st)) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
+      psg_rank_free(rk);
+      ++inner_passes; inner_suffixes += T;
+      mbv[(size_t)i].alloc(4 * ((c.size + T + 31) / 32 + 2), true);
+      int64_t nb = 0;
+      CK(psg_gap_to_bitvector(gap.as<uint32_t>(), c.size, mbv[(size_t)i].as<uint32_t>(), c.size + T, &nb));
+      if (nb != c.size + T) throw std::runtime_error("gap sum mismatch in a sub-range pass");
+      CK(psg_bitcopy(gt_n.as<uint32_t>(), T, c.gt.as<uint32_t>(), 0, c.size));   // positions (c.beg, x1]
+      std::swap(gt_c, gt_n);
+    }
+    std::vector<psg_hb_desc> desc((size_t)f);
+    for (int i = 0; i < f; ++i)
+      desc[(size_t)i] = psg_hb_desc{ch[(size_t)i].beg - b, ch[(size_t)i].size, ch[(size_t)i].psa.as<uint32_t>(), nullptr, i + 1 < f ? mbv[(size_t)i].as<uint32_t>() : nullptr};
+    psg_merge_plan_t *plan = nullptr;
+    CK(psg_merge_plan_create(desc.data(), f, &plan));
+    DevNode out;
+    out.beg = b; out.size = R;
+    out.psa.alloc(4 * R + 16);
+    int mrc = psg_merge_run_u32(plan, 0, R, out.psa.as<uint32_t>());
+    psg_merge_plan_free(plan);
+    if (mrc) throw std::runtime_error(std::string("psg_merge_run_u32: ") + psg_last_error());
+    ch.clear();                                               // the children's arrays are dead
+    out.bwt.alloc(R + 16);
+    out.gt.alloc(4 * gtw, true);
+    CK(psg_halfblock_from_psa(&sc_text, b, R, out.psa.as<uint32_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()));
+    return out;
+  };
+  const int fanout = std::max(2, opt.fanout);
+  std::function<DevNode(std::vector<std::unique_ptr<HalfBlock>> &, size_t, size_t)> build_tree =
+      [&](std::vector<std::unique_ptr<HalfBlock>> &lv, size_t lo, size_t hi) -> DevNode {
+    if (hi - lo == 1) { DevNode d = upload_leaf(*lv[lo]); lv[lo].reset(); return d; }
+    std::vector<DevNode> ch;
+    const size_t cnt = hi - lo, groups = std::min<size_t>((size_t)fanout, cnt);
+    for (size_t g = 0; g < groups; ++g) ch.push_back(build_tree(lv, lo + cnt * g / groups, lo + cnt * (g + 1) / groups));
+    return merge_nodes(ch);
+  };
+
+  // one half-block, ready for the block schedule: BWT and gt_begin in HBM, the partial SA in host memory
+  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; std::vector<uint32_t> psa_lo; std::vector<uint8_t> psa_hi; std::vector<uint32_t> gt_host; };
+  auto gt_host_of = [&](Half &h) -> const std::vector<uint32_t> & {   // gt_begin on the host (sequential sorter of the half to the left)
+    if (h.gt_host.empty()) { h.gt_host.resize((size_t)((h.size + 31) / 32 + 1)); CK(psg_d2h(h.gt_host.data(), h.gt.p, 4 * (int64_t)h.gt_host.size())); }
+    return h.gt_host;
+  };
+  auto make_half = [&](int64_t id, int64_t hb, int64_t he, const psa_host::GtTail &gt_tail, const char *what) {
+    Half H;
+    H.beg = hb; H.size = he - hb;
+    const double t0 = wclock();
+    if (opt.device_sort && H.size < ((int64_t)1 << 32)) {
+      Dev psa(4 * H.size + 16), bwt(H.size + 16), gt(4 * ((H.size + 31) / 32 + 2), true);
+      int64_t i0 = -1, ties = 0;
+      if (psgx_sort_halfblock(d_text.as<uint8_t>(), n, hb, he, psa.as<uint32_t>(), bwt.as<uint8_t>(), &i0, gt.as<uint32_t>(), &ties) == 0) {
+        H.i0 = i0;
+        H.psa_lo.resize((size_t)H.size);
+        CK(psg_d2h(H.psa_lo.data(), psa.p, 4 * H.size));
+        H.bwt = std::move(bwt); H.gt = std::move(gt);
+        log_phase((std::string("device sufsort (") + what + " half)").c_str(), t0, H.size);
+        return H;
+      }
+      fprintf(stderr, "    device sufsort (%s half) gave up (%s): host sorter\n", what, psg_last_error());
+    }
+    std::vector<std::unique_ptr<HalfBlock>> leaves = take_leaves(id);
+    const double t_wait = wclock() - t0;
+    auto from_host = [&](HalfBlock &h) {
+      H.i0 = h.i0;
+      H.bwt = upload(h.bwt.data(), h.size);
+      H.gt = upload(h.gt_begin.data(), 4 * (int64_t)h.gt_begin.size());
+      H.gt_host.swap(h.gt_begin);
+      H.psa_lo.swap(h.psa_lo); H.psa_hi.swap(h.psa_hi);
+    };
+    if (leaves.empty()) {                                     // sequential schedule: one sort with gt bits
+      HalfBlock h;
+      psa_host::sort_halfblock(text.data(), n, hb, he, gt_tail, h);
+      from_host(h);
+      fprintf(stderr, "    host sufsort (%s half): %.2fs (%.2f MiB/s)\n", what, wclock() - t0, H.size / 1048576.0 / std::max(wclock() - t0, 1e-9));
+    } else if (leaves.size() == 1) {
+      from_host(*leaves[0]);
+      fprintf(stderr, "    host sufsort (%s half, sorted ahead; waited): %.2fs\n", what, t_wait);
+    } else {
+      const size_t nl = leaves.size();
+      const int64_t p0 = inner_passes, s0 = inner_suffixes;
+      DevNode root = build_tree(leaves, 0, nl);
+      H.i0 = root.i0;
+      H.psa_lo.resize((size_t)H.size);
+      CK(psg_d2h(H.psa_lo.data(), root.psa.p, 4 * H.size));
+      H.bwt = std::move(root.bwt); H.gt = std::move(root.gt);
+      fprintf(stderr, "    sufsort (%s half): %zu leaves sorted ahead on the host (waited %.2fs), merged on the device in %.2fs (%ld passes, %.1f Mi suffixes streamed)\n",
+              what, nl, t_wait, wclock() - t0 - t_wait, (long)(inner_passes - p0), (inner_suffixes - s0) / 1048576.0);
+    }
+    return H;
+  };
+  auto keep_half = [&](Half &h) {   // the partial SA stays on the host; everything else of the half-block is dropped
+    DoneHalfBlock d;
+    d.beg = h.beg; d.size = h.size;
+    d.psa_lo.swap(h.psa_lo); d.psa_hi.swap(h.psa_hi);
+    return d;
   };
 
   for (int64_t bid = n_blocks - 1; bid >= 0; --bid) {   // partial_sufsort.hpp:568
@@ -365,49 +536,42 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t rs = bs - ls, mid = b + ls;
     fprintf(stderr, "Process block %ld/%ld [%ld..%ld):\n", (long)(n_blocks - bid), (long)n_blocks, (long)b, (long)e);
     CK(psg_memset(gt_new.p, 0, gt_new.bytes));
-    if (!last_block) { cur_host.resize((size_t)gt_words); CK(psg_d2h(cur_host.data(), gt_cur.p, 4 * gt_words)); }
-    auto gt_tail_e = [&](int64_t v) { int64_t idx = n - (e + v); return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u); };
-    HalfBlock R, L;
-    double t0 = wclock();
-    if (rs == 0 && lookahead) { std::lock_guard<std::mutex> lk(pre_mu); ++consumed; pre_cv.notify_all(); }   // its (empty) right-half task
-    if (rs > 0) {
-      if (auto p = take_pre(2 * bid + 1)) { R = std::move(*p); log_phase("host sufsort (right half, sorted ahead; waited)", t0, rs); }
-      else {
-        psa_host::sort_halfblock(text.data(), n, mid, e, gt_tail_e, R);
-        log_phase("host sufsort (right half)", t0, rs);
-      }
-    }
+    bool have_cur_host = false;
+    auto gt_tail_e = [&](int64_t v) {     // [text[e+v..) > text[e..)] from the previous block's passes (fetched when a sequential sort asks)
+      if (!have_cur_host) { cur_host.resize((size_t)gt_words); CK(psg_d2h(cur_host.data(), gt_cur.p, 4 * gt_words)); have_cur_host = true; }
+      int64_t idx = n - (e + v);
+      return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u);
+    };
+    Half R, L;
+    if (rs > 0) R = make_half(2 * bid + 1, mid, e, gt_tail_e, "right");
     auto gt_tail_mid = [&](int64_t v) {  // position mid+v in (mid, e]: right half's gt_begin, u = e - j
       if (rs == 0) return gt_tail_e(v);
       int64_t u = e - (mid + v);
-      return (bool)((R.gt_begin[(size_t)(u >> 5)] >> (u & 31)) & 1u);
+      return (bool)((gt_host_of(R)[(size_t)(u >> 5)] >> (u & 31)) & 1u);
     };
-    t0 = wclock();
-    if (auto p = take_pre(2 * bid)) { L = std::move(*p); log_phase("host sufsort (left half, sorted ahead; waited)", t0, ls); }
-    else {
-      psa_host::sort_halfblock(text.data(), n, b, mid, gt_tail_mid, L);
-      log_phase("host sufsort (left half)", t0, ls);
-    }
-    Dev d_lgt = upload(L.gt_begin.data(), 4 * (int64_t)L.gt_begin.size());
+    L = make_half(2 * bid, b, mid, gt_tail_mid, "left");
+    double t0 = wclock();
     if (rs == 0) {
-      DoneHalfBlock hbL = keep_hb(L);
-      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      DoneHalfBlock hbL = keep_half(L);
       if (opt.spill_psa) hbL.spill(opt.gap_prefix);
+      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, L.gt.as<uint32_t>(), 0, ls));
       hbs.push_back(std::move(hbL));
       std::swap(gt_cur, gt_new);
       continue;
     }
-    Dev d_lbwt = upload(L.bwt.data(), ls), d_rbwt = upload(R.bwt.data(), rs);
-    Dev d_rgt = upload(R.gt_begin.data(), 4 * (int64_t)R.gt_begin.size());
+    Dev &d_lbwt = L.bwt, &d_rbwt = R.bwt, &d_rgt = R.gt, &d_lgt = L.gt;
     // ---- pass A (partial_sufsort.hpp:403-414)
     t0 = wclock();
     psg_rank_t *rankL = nullptr;
     CK(psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL));
     log_phase("Construct rank (left half, device)", t0, ls);
     Dev gapA(4 * psg_gap_words(ls), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
-    int64_t initA = psa_host::rank_by_search(text.data(), n, L, e);
+    HalfBlock Lview;                                          // rank of text[e..) among the left half's suffixes: host search over its partial SA
+    Lview.beg = b; Lview.size = ls; Lview.psa_lo.swap(L.psa_lo); Lview.psa_hi.swap(L.psa_hi);
+    int64_t initA = psa_host::rank_by_search(text.data(), n, Lview, e);
+    L.psa_lo.swap(Lview.psa_lo); L.psa_hi.swap(Lview.psa_hi);
     const int64_t L_i0 = L.i0, R_i0 = R.i0;
-    DoneHalfBlock hbL = keep_hb(L), hbR = keep_hb(R);
+    DoneHalfBlock hbL = keep_half(L), hbR = keep_half(R);
     psg_stream_stats st;
     t0 = wclock();
     stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
@@ -462,6 +626,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
   }
+  if (inner_passes) fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
   gt_cur.release(); gt_new.release();
   if (opt.check_samples < 0) d_text.release();     // the device-side check compares suffixes of the text
 
@@ -512,7 +677,9 @@ int main(int argc, char **argv) {
                                          {"output", required_argument, NULL, 'o'}, {"verbose", no_argument, NULL, 'v'},
                                          {"block-size", required_argument, NULL, 1000}, {"chains", required_argument, NULL, 1001},
                                          {"check", optional_argument, NULL, 1002}, {"discard-output", no_argument, NULL, 1003},
-                                         {"spill-psa", no_argument, NULL, 1004}, {NULL, 0, NULL, 0}};
+                                         {"spill-psa", no_argument, NULL, 1004}, {"leaf-size", required_argument, NULL, 1005},
+                                         {"fanout", required_argument, NULL, 1006}, {"no-device-merge", no_argument, NULL, 1007},
+                                         {"device-sort", no_argument, NULL, 1008}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
   Options opt;
@@ -532,6 +699,10 @@ int main(int argc, char **argv) {
       case 1002: opt.check_samples = optarg ? atoll(optarg) : 4096; if (opt.check_samples < 0) opt.check_samples = 0; break;
       case 1003: opt.discard = true; break;
       case 1004: opt.spill_psa = true; break;
+      case 1005: { uint64_t v; if (!parse_number(optarg, &v) || v == 0) { fprintf(stderr, "Error: bad --leaf-size\n\n"); usage(EXIT_FAILURE); } opt.leaf_size = (int64_t)v; break; }
+      case 1006: opt.fanout = atoi(optarg); break;
+      case 1007: opt.hierarchical = false; break;
+      case 1008: opt.device_sort = true; break;
       default: usage(EXIT_FAILURE); break;
     }
   }

@@ -191,8 +191,28 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   const double info = sigma >= 2 ? std::log2((double)sigma) / bits : 1.0;
   int need = std::min(used, (int)std::ceil((lg + 8) / info));
   if (need > 32 && (int)std::ceil((lg + 5) / info) <= 32) need = 32;   // the packed 32-bit path below; groups a little larger
+  // Is this text for the prefix-key sorter at all?  4096 evenly spaced suffixes: if more than a few of them share their
+  // whole sort key with another sample, every suffix shares it with many (natural language: ~20 per key at 2 MiB), the
+  // group sorts dominate and SA-IS is twice as fast -- decided before the radix passes are paid for.
+  if (m >= (1 << 16)) {
+    const int S = 4096;
+    std::vector<uint64_t> sk((size_t)S);
+    for (int q = 0; q < S; ++q) {
+      const int64_t i = beg + (m / S) * q;
+      uint64_t k = 0;
+      for (int t = 0; t < per_key; ++t) k = (k << bits) | (i + t < n ? code[text[i + t]] : 0);
+      sk[(size_t)q] = need >= 64 ? k : ((k << (64 - used)) >> (64 - need));
+    }
+    std::sort(sk.begin(), sk.end());
+    int ties = 0;
+    for (int q = 1; q < S; ++q) ties += sk[(size_t)q] == sk[(size_t)q - 1];
+    if (ties > S / 128) return false;
+  }
   std::vector<uint32_t> idx((size_t)m);
-  int64_t budget = 64 * m + (1 << 20);   // total symbol comparisons allowed before SA-IS is the better tool
+  // total symbol comparisons allowed before SA-IS is the better tool: text with repeats of tens of symbols (natural
+  // language) spends ~50 comparisons per suffix in the group sorts and runs at half of SA-IS's speed, random text
+  // needs about one -- so the budget is small and the sorter gives up early
+  int64_t budget = 12 * m + (1 << 16);
   // text[beg+a ..n) < text[beg+b ..n) for two suffixes known to agree on their first `known` symbols
   auto less_from = [&](uint32_t a, uint32_t b, int known) {
     int64_t x = beg + a + known, y = beg + b + known;

@@ -230,6 +230,19 @@ int psg_merge_plan_create(const psg_hb_desc *hbs, int H, psg_merge_plan_t **out)
 int psg_merge_run(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint8_t *d_out_sa5);
 void psg_merge_plan_free(psg_merge_plan_t *plan);
 
+/* ---- in-memory pSAscan pieces (inmem_psascan_src/inmem_psascan.hpp:64-304): a range too large for one host sort
+ *      is cut into sub-ranges that ARE sorted on the host; their partial SAs are merged on the device exactly like
+ *      the blocks of the text (one streaming pass per sub-range over the sub-ranges to its right, gap ->
+ *      bitvector, psg_merge_plan_create), which yields the range's own partial SA:                          */
+/* the merged order of a plan as u32 values: every level's beg + psa value must be below 2^32, i.e. the plan's
+ * `beg` are relative to the enclosing range                                                                  */
+int psg_merge_run_u32(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint32_t *d_out);
+/* BWT (dummy 0 at i0, inmem_bwt_from_sa.hpp:47-83), i0 and gt_begin (bit u <-> position beg + size - u: the suffix
+ * is ranked after the range's first suffix; bit 0 by comparison) of text[beg .. beg + size) from its partial SA.
+ * sc: text + comparison end + gt bits as for psg_initial_ranks (parts unused); d_gt_begin may be NULL.        */
+int psg_halfblock_from_psa(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa, uint8_t *d_bwt,
+                           int64_t *i0, uint32_t *d_gt_begin);
+
 /* ---- merge<T> with the partial suffix arrays in HOST memory.  The reference keeps every partial SA in part files
  *      (io/distributed_file.hpp:58-67) and streams them back during the merge (merge.hpp:72-81, 143; parts
  *      deleted as consumed, distributed_file.hpp:159-171); here they stay where the host sorter left them and

@@ -105,6 +105,8 @@ SIGNATURES = {
     "psg_merge_plan_create": (_int, [C.POINTER(HbDescC), _int, C.POINTER(_vp)]),
     "psg_merge_run": (_int, [_vp, _i64, _i64, _vp]),
     "psg_merge_plan_free": (None, [_vp]),
+    "psg_merge_run_u32": (_int, [_vp, _i64, _i64, _vp]),
+    "psg_halfblock_from_psa": (_int, [C.POINTER(SearchCtxC), _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
     "psg_bits_rank1": (_int, [_vp, _i64, C.POINTER(_i64), _i64, C.POINTER(_i64)]),
     "psg_merge_plan_create_sliced": (_int, [C.POINTER(HbSliceDescC), _int, C.POINTER(_vp)]),
     "psg_merge_stream": (_int, [C.POINTER(HbHostDescC), _int, _i64, C.POINTER(MergeCheckC), SINK_FN, _vp, C.POINTER(MergeStreamStatsC)]),

@@ -561,7 +561,9 @@ __device__ __forceinline__ void merge_level_loads(const MergeLevel &L, i64 q0, i
 // positions of the current level: its own elements (bit 0) are consecutive elements of this half-block's PSA
 // and are gathered straight into the output slots, its survivors (bit 1) are compacted -- slot numbers only --
 // into the other slot buffer and form a contiguous range of the next level.
-template <bool HI>
+// OUT32: the values (below 2^32: positions inside one half-block) leave as plain u32 instead of packed uint40 -- the
+// merge of sub-blocks into a half-block's partial SA (in-memory pSAscan, inmem_psascan.hpp:64-304)
+template <bool HI, bool OUT32 = false>
 __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out) {
   __shared__ u32 scratch[8];
   __shared__ __attribute__((aligned(16))) u16 cur[2][MT];
@@ -622,6 +624,11 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
     q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
   }
   __syncthreads();
+  if (OUT32) {
+    u32 *o32 = (u32 *)out + (x0 - out_begin);
+    for (int k = threadIdx.x; k < len; k += PSG_WG) o32[k] = vlo[k];
+    return;
+  }
   // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords, staged in LDS (the slot
   // buffers are dead now) so that the tile leaves as whole 16-byte stores
   u32 *packed = (u32 *)&cur[0][0];                 // 8 KiB: half a tile (1024 entries = 5 KiB) at a time
@@ -787,6 +794,21 @@ static int merge_launch(int H, const MergeLevel *d_levels, const MergeLevel &L0,
     else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out);
   }
   PSG_HIP(hipGetLastError());
+  return 0;
+}
+
+// the merged order as u32 values (every beg + psa value must be below 2^32: the plan's `beg` are relative to the
+// enclosing range).  Replaces the merging stage of the reference's in-memory sorter (inmem_psascan.hpp:233-304).
+extern "C" int psg_merge_run_u32(const psg_merge_plan_t *p, int64_t out_begin, int64_t out_count, uint32_t *d_out) {
+  PSG_REQUIRE(p && d_out && out_begin >= 0 && out_count >= 0 && out_begin + out_count <= p->n, "psg_merge_run_u32: range");
+  for (const MergeLevel &L : p->levels) PSG_REQUIRE(!L.hi && L.beg + L.size <= 0x100000000ll, "psg_merge_run_u32: values must fit 32 bits");
+  if (out_count == 0) return 0;
+  EventTimer tm; tm.start();
+  hipLaunchKernelGGL((merge_kernel<false, true>), dim3((unsigned)cdiv(out_count, MT)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_out);
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(psg::sync_stream());
+  note_kernel_ms(tm.ms());
   return 0;
 }
 

@@ -131,3 +131,53 @@ extern "C" int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_posi
   note_kernel_ms(tm.ms());
   return 0;
 }
+
+// =======================================================================================
+// BWT, i0 and gt_begin of a range from its partial suffix array (inmem_bwt_from_sa.hpp:47-83;
+// gt_begin: compute_initial_gt_bitvectors.hpp -- here simply "ranked after the range's first suffix")
+// =======================================================================================
+__global__ __launch_bounds__(PSG_WG) void psa_find_i0_kernel(const u32 *psa, i64 size, i64 *i0) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k < size && psa[k] == 0) *i0 = k;
+}
+// bwt[k] = text[beg + psa[k] - 1] (dummy 0 at i0); gt bit u = size - s for every suffix s ranked after suffix 0
+__global__ __launch_bounds__(PSG_WG) void psa_bwt_gt_kernel(const u8 *text, i64 beg, i64 size, const u32 *psa, const i64 *i0p, u8 *bwt, u32 *gt) {
+  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
+  if (k >= size) return;
+  const i64 i0 = *i0p;
+  const u32 s = psa[k];
+  bwt[k] = s ? text[beg + s - 1] : 0;
+  if (gt && s && k > i0) { const i64 u = size - s; atomicOr(&gt[u >> 5], 1u << (u & 31)); }
+}
+
+extern "C" int psg_halfblock_from_psa(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa, uint8_t *d_bwt,
+                                      int64_t *i0, uint32_t *d_gt_begin) {
+  PSG_REQUIRE(sc && sc->d_text && d_psa && d_bwt && i0 && size >= 1 && beg >= 0 && beg + size <= sc->n && size < 0x100000000ll, "psg_halfblock_from_psa");
+  DevBuf misc;
+  if (int rc = misc.alloc(16)) return rc;
+  PSG_HIP(hipMemsetAsync(misc.p, 0xFF, 16, stream()));
+  const unsigned grid = (unsigned)cdiv(size, PSG_WG);
+  hipLaunchKernelGGL(psa_find_i0_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), d_psa, size, misc.as<i64>());
+  if (d_gt_begin) PSG_HIP(hipMemsetAsync(d_gt_begin, 0, (size_t)(((size + 31) >> 5) * 4), stream()));
+  hipLaunchKernelGGL(psa_bwt_gt_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), sc->d_text, beg, size, d_psa, misc.as<i64>(), d_bwt, d_gt_begin);
+  PSG_HIP(hipGetLastError());
+  i64 h = -1;
+  if (int rc = psg::copy_d2h(&h, misc.p, 8)) return rc;
+  if (h < 0 || h >= size) { set_error("psg_halfblock_from_psa: the partial suffix array does not contain the range's first suffix"); return PSG_ECHECK; }
+  *i0 = h;
+  // bit u = 0 (position beg + size): [text[end..) > text[beg..)] = the first suffix is NOT smaller... decided by search: rank of `end` among {beg}
+  if (d_gt_begin && beg + size < sc->n) {
+    psg_search_ctx one = *sc;
+    const u32 zero = 0;
+    DevBuf z;
+    if (int rc = z.alloc(16)) return rc;
+    PSG_HIP(hipMemsetAsync(z.p, 0, 16, stream()));
+    (void)zero;
+    one.nparts = 1; one.part[0].beg = beg; one.part[0].size = 1; one.part[0].d_psa_lo = z.as<u32>(); one.part[0].d_psa_hi = nullptr;
+    const int64_t pos = beg + size;
+    int64_t r = 0;
+    if (int rc = psg_initial_ranks(&one, &pos, 1, &r)) return rc;     // r = [text[beg..) < text[end..)]
+    if (r == 1) { u32 w; if (int rc = psg::copy_d2h(&w, d_gt_begin, 4)) return rc; w |= 1u; if (int rc = psg::copy_h2d(d_gt_begin, &w, 4)) return rc; }
+  }
+  return 0;
+}
