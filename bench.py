@@ -47,10 +47,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PMC_TRAFFIC_B_PER_SUFFIX = {8.3: 71.5, 16.0: 71.4}
 
 
-def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True):
-    """The whole construct_sa program (host/construct_sa: map the file, host suffix sort of the half-blocks on the
-    host threads, the device passes, streamed merge, write the .sa5) on a bounded sample, as a child process, with
-    its own device-side check of the output (--check).  It is bound by the host sorter, not by the GPU."""
+def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True, device_sort=False):
+    """The whole construct_sa program with its defaults (-m 3584Mi, block size from the reference's formula) on a
+    bounded sample, as a child process: map the file, suffix-sort the half-blocks (host cores: leaves sorted by SA-IS /
+    prefix-key sorter on the host threads and merged on the device; device_sort=True: the --device-sort extension),
+    the device passes, streamed merge, .sa5 to a file, the program's own device-side check of the output (--check)."""
     import subprocess
     import tempfile
     import numpy as np
@@ -62,13 +63,16 @@ def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True):
     with tempfile.TemporaryDirectory() as d:
         f = os.path.join(d, "sample.bin")
         if english and api is not None:
-            d_t = extras.gen_text(n, extras.MODE_ENGLISH, 0, seed=11)
-            api.download(d_t, np.uint8, n).tofile(f)
-            d_t.free()
+            with open(f, "wb") as fh:
+                for off in range(0, n, 1 << 30):
+                    c = min(1 << 30, n - off)
+                    d_t = extras.gen_text(c, extras.MODE_ENGLISH, 0, seed=11 + (off >> 30))
+                    api.download(d_t, np.uint8, c).tofile(fh)
+                    d_t.free()
         else:
             np.random.default_rng(11).integers(0, 255, n, dtype=np.uint8).tofile(f)
         t0 = time.time()
-        r = subprocess.run([cli, "-m", "8G", "--block-size", str(32 << 20), "--check=1024", f], capture_output=True, text=True,
+        r = subprocess.run([cli, "--check=1024", f] + (["--device-sort"] if device_sort else []), capture_output=True, text=True,
                            env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=900)
         wall = time.time() - t0
         ok = r.returncode == 0 and os.path.getsize(f + ".sa5") == 5 * n and "permutation sum ok, 0 of" in r.stderr
@@ -76,9 +80,12 @@ def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True):
         log("construct_sa failed:", r.stderr[-300:])
         return {"value": None, "unit": "MB/s", "sample": "failed"}
     peak = [l.strip() for l in r.stderr.splitlines() if "device memory" in l]
+    inner = [l.strip() for l in r.stderr.splitlines() if "In-HBM merging" in l]
     return {"value": n / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2), "output_check": "permutation sum ok, 0 sampled pairs out of order",
-            "device_memory": peak[0] if peak else None,
-            "sample": f"{sample_mib} MiB {'English-like text' if english else 'uniform bytes 0..254'} from a file, 32 MiB blocks, host suffix sort on {threads} threads, .sa5 written to a file; wall time of the child process"}
+            "device_memory": peak[0] if peak else None, "leaf_merging": inner[0] if inner else None,
+            "sample": f"{sample_mib} MiB {'English-like text' if english else 'uniform bytes 0..254'} from a file, default -m (646 MiB blocks), "
+                      + ("half-blocks sorted on the device (--device-sort, not the reference's placement)" if device_sort else f"half-blocks sorted on {threads} host threads as 2 MiB leaves and merged on the device")
+                      + ", .sa5 written to a file; wall time of the child process"}
 
 
 def parse():
@@ -660,7 +667,8 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
         if not args.no_secondary:
             try:
-                res["end_to_end_cli"] = end_to_end_cli(1024, log, api, extras, english=args.text == "english")
+                res["end_to_end_cli"] = end_to_end_cli(2048, log, api, extras, english=args.text == "english")
+                res["end_to_end_cli_device_sort"] = end_to_end_cli(2048, log, api, extras, english=args.text == "english", device_sort=True)
             except Exception as e:
                 res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}
             try:

@@ -398,9 +398,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // becomes its merge bitvector, one merge yields the union's partial SA; BWT, i0 and gt_begin follow from it.
   struct DevNode { int64_t beg = 0, size = 0, i0 = 0; Dev psa, bwt, gt; };
   int64_t inner_passes = 0, inner_suffixes = 0;
+  double tm_upload = 0, tm_search = 0, tm_rank = 0, tm_stream = 0, tm_bv = 0, tm_merge = 0, tm_finish = 0;   // where the merging spends its time
   psg_search_ctx sc_text{};                                  // comparisons by reading on in the text (cmp_end = n)
   sc_text.d_text = d_text.as<uint8_t>(); sc_text.n = n; sc_text.cmp_end = n; sc_text.d_gt_cmp_end = nullptr; sc_text.nparts = 0;
   auto upload_leaf = [&](HalfBlock &h) {
+    const double tu = wclock();
+    struct Acc { double &a; double t0; ~Acc() { a += wclock() - t0; } } acc{tm_upload, tu};
     DevNode d;
     d.beg = h.beg; d.size = h.size; d.i0 = h.i0;
     d.psa = upload(h.psa_lo.data(), 4 * h.size);
@@ -421,9 +424,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       psg_search_ctx sc = sc_text;
       sc.nparts = 1; sc.part[0].beg = c.beg; sc.part[0].size = c.size; sc.part[0].d_psa_lo = c.psa.as<uint32_t>(); sc.part[0].d_psa_hi = nullptr;
       int64_t r_end = 0;
+      double tq = wclock();
       if (e < n) CK(psg_initial_ranks(&sc, &e, 1, &r_end));
+      tm_search += wclock() - tq; tq = wclock();
       psg_rank_t *rk = nullptr;
       CK(psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk));
+      tm_rank += wclock() - tq; tq = wclock();
       Dev gap(4 * psg_gap_words(c.size), false);
       CK(psg_memset(gt_n.p, 0, gt_n.bytes));
       psg_stream_args a{};
@@ -433,6 +439,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       psg_stream_stats st;
       if (psg_stream_gap_args(&a, nullptr, &st)) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
       psg_rank_free(rk);
+      tm_stream += wclock() - tq; tq = wclock();
       ++inner_passes; inner_suffixes += T;
       mbv[(size_t)i].alloc(4 * ((c.size + T + 31) / 32 + 2), true);
       int64_t nb = 0;
@@ -440,7 +447,9 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       if (nb != c.size + T) throw std::runtime_error("gap sum mismatch in a sub-range pass");
       CK(psg_bitcopy(gt_n.as<uint32_t>(), T, c.gt.as<uint32_t>(), 0, c.size));   // positions (c.beg, x1]
       std::swap(gt_c, gt_n);
+      tm_bv += wclock() - tq;
     }
+    double tq = wclock();
     std::vector<psg_hb_desc> desc((size_t)f);
     for (int i = 0; i < f; ++i)
       desc[(size_t)i] = psg_hb_desc{ch[(size_t)i].beg - b, ch[(size_t)i].size, ch[(size_t)i].psa.as<uint32_t>(), nullptr, i + 1 < f ? mbv[(size_t)i].as<uint32_t>() : nullptr};
@@ -453,9 +462,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     psg_merge_plan_free(plan);
     if (mrc) throw std::runtime_error(std::string("psg_merge_run_u32: ") + psg_last_error());
     ch.clear();                                               // the children's arrays are dead
+    tm_merge += wclock() - tq; tq = wclock();
     out.bwt.alloc(R + 16);
     out.gt.alloc(4 * gtw, true);
     CK(psg_halfblock_from_psa(&sc_text, b, R, out.psa.as<uint32_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()));
+    tm_finish += wclock() - tq;
     return out;
   };
   const int fanout = std::max(2, opt.fanout);
@@ -626,7 +637,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
   }
-  if (inner_passes) fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
+  if (inner_passes) {
+    fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
+    if (g_verbose) fprintf(stderr, "    seconds: leaf upload %.2f, start-rank search %.2f, rank build %.2f, stream pass %.2f, gap->bitvector %.2f, merge %.2f, BWT/gt from PSA %.2f\n",
+                           tm_upload, tm_search, tm_rank, tm_stream, tm_bv, tm_merge, tm_finish);
+  }
   gt_cur.release(); gt_new.release();
   if (opt.check_samples < 0) d_text.release();     // the device-side check compares suffixes of the text
 

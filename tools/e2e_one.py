@@ -17,9 +17,10 @@ if not os.path.exists(f):
             d_t = extras.gen_text(c, extras.MODE_ENGLISH if kind == "english" else extras.MODE_BYTES255 if kind == "bytes" else extras.MODE_DNA, 0, seed=11 + off // chunk)
             api.download(d_t, np.uint8, c).tofile(fh)
             d_t.free()
+            print(f"generated {off + c >> 20} MiB", flush=True)
 api.lib().psg_trim()
+print("input file ready", flush=True)
 t0 = time.time()
-r = subprocess.run(["host/construct_sa"] + sys.argv[3:] + [f], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="16"))
+r = subprocess.run(["host/construct_sa"] + sys.argv[3:] + [f], stdout=sys.stdout, stderr=sys.stdout, text=True, env=dict(os.environ, OMP_NUM_THREADS="16"))   # the log streams through
 dt = time.time() - t0
-print(r.stderr[-6000:])
-print(f"rc={r.returncode} {kind} {mib} MiB: {dt:.2f} s = {n / 1e6 / dt:.1f} MB/s")
+print(f"rc={r.returncode} {kind} {mib} MiB: {dt:.2f} s = {n / 1e6 / dt:.1f} MB/s", flush=True)
