@@ -49,7 +49,7 @@ void pool_trim();
 size_t pool_cached_bytes();   // bytes held in the cache (reusable without asking the driver)
 
 // grow-only pinned host buffers (slot 0..15): 0-3 stream pass (per-chain arrays, read-backs), 4 wide-log slab
-// bounds, 7 copy staging, 8-11 streamed merge (PSA pieces in, .sa5 slices out), 12 merge cursors
+// bounds, 7 copy staging, 8-11 streamed merge (PSA pieces in, .sa5 slices out), 12 merge cursors, 13 the LDS tables of a pass; 5-6 search positions / ranks
 void *pinned_buf(int slot, size_t bytes);
 // Synchronous host<->device copies staged through pinned memory.  Pageable host pointers are never
 // handed to HIP: ROCr registers them as userptr ranges, and when the host later unmaps / trims

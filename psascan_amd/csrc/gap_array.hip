@@ -24,10 +24,9 @@ int psg::gap_prepare(u32 *d_gap, i64 m, bool fresh, int *bits) {
     if (h[1] != 0) { *bits = (int)h[1]; return 0; }          // an array in use keeps its width
     if (h[0] != 0) { set_error("gap array: excess entries without a counter width (array not initialised?)"); return PSG_EINVAL; }
   }
-  h[0] = 0; h[1] = (u32)want; h[2] = 0; h[3] = 0;
-  memcpy(pinned_buf(3, 64), h, 16);
-  PSG_HIP(hipMemcpyAsync(hdr, pinned_buf(3, 64), 16, hipMemcpyHostToDevice, stream()));
-  PSG_HIP(psg::sync_stream());
+  // header = {0 entries, `want` bits, no flag, default capacity}: two memsets, no host round trip
+  PSG_HIP(hipMemsetAsync(hdr, 0, 16, stream()));
+  PSG_HIP(hipMemsetAsync((char *)hdr + 4, want, 1, stream()));
   *bits = want;
   return 0;
 }

@@ -869,7 +869,12 @@ extern "C" int64_t psg_rank_device_bytes(const psg_rank_t *r) { return r ? r->bl
 
 // T1[sb][c] = (Cadd[c] + sb_base[sb][code[c]]) | code << 56 ; tot[c] = count[c]
 static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &tot) {
-  std::vector<u64> h((size_t)r->nsb * 256), t(512, 0);
+  // built in a pinned buffer and copied asynchronously: the kernels that read the tables are ordered behind the copy on
+  // the stream, and the next call (which reuses the buffer) only comes after this pass has been waited for
+  const size_t n1 = (size_t)r->nsb * 256;
+  u64 *h = (u64 *)pinned_buf(13, (n1 + 512) * 8);
+  if (!h) { set_error("make_tables: pinned host allocation failed"); return PSG_ENOMEM; }
+  u64 *t = h + n1;
   for (int s = 0; s < r->nsb; ++s)
     for (int c = 0; c < 256; ++c) {
       u8 cd = r->code[c];
@@ -877,11 +882,10 @@ static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &t
       h[(size_t)s * 256 + c] = ((u64)(Cadd ? Cadd[c] : 0) + base) | ((u64)cd << CODE_SHIFT);
     }
   for (int c = 0; c < 256; ++c) { t[c] = (u64)r->count[c]; t[256 + c] = r->t2[c]; }
-  if (int rc = T1.alloc((i64)h.size() * 8)) return rc;
+  if (int rc = T1.alloc((i64)n1 * 8)) return rc;
   if (int rc = tot.alloc(512 * 8)) return rc;
-  if (int rc_ = psg::copy_h2d(T1.p, h.data(), (size_t)(h.size() * 8))) return rc_;
-  if (int rc_ = psg::copy_h2d(tot.p, t.data(), (size_t)(512 * 8))) return rc_;
-  PSG_HIP(psg::sync_stream());  // h, t go out of scope
+  PSG_HIP(hipMemcpyAsync(T1.p, h, n1 * 8, hipMemcpyHostToDevice, stream()));
+  PSG_HIP(hipMemcpyAsync(tot.p, t, 512 * 8, hipMemcpyHostToDevice, stream()));
   return 0;
 }
 

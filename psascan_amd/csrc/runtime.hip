@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -231,7 +232,7 @@ void *pinned_buf(int slot, size_t bytes) {
 // Pinned host memory (psg_host_alloc, torch pinned tensors) is copied by one DMA.  Pageable memory goes through
 // TWO pinned staging buffers: the host fills one while the DMA drains the other, and the only waits are for the
 // buffer about to be refilled (was: one buffer, a full stream sync per 32 MiB piece).
-static const size_t STAGE_BYTES = (size_t)16 << 20;
+static const size_t STAGE_BYTES = (size_t)32 << 20;
 static bool is_pinned_host(const void *p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -246,15 +247,31 @@ static hipError_t wait_event_poll(hipEvent_t e) {
   }
   return rc;
 }
+// pageable <-> pinned copies of a piece with a few helper threads: one core moves ~30 GiB/s (and takes page faults on
+// fresh memory one at a time), the PCIe link 50 GiB/s
+static void host_copy(char *dst, const char *src, size_t n) {
+  const size_t MINPAR = (size_t)4 << 20;
+  if (n < MINPAR) { memcpy(dst, src, n); return; }
+  const int nt = 4;
+  std::thread th[nt - 1];
+  const size_t per = (n / nt + 4095) & ~(size_t)4095;
+  for (int t = 1; t < nt; ++t) {
+    const size_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+    th[t - 1] = std::thread([=] { if (b > a) memcpy(dst + a, src + a, b - a); });
+  }
+  memcpy(dst, src, std::min(n, per));
+  for (int t = 1; t < nt; ++t) th[t - 1].join();
+}
+
 int copy_h2d(void *d, const void *h, size_t bytes) {
   if (bytes >= ((size_t)1 << 16) && is_pinned_host(h)) {
     PSG_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream()));
     PSG_HIP(sync_stream());
     return 0;
   }
-  char *pin = (char *)pinned_buf(7, 2 * std::min(STAGE_BYTES, std::max<size_t>(bytes, 4096)));
-  if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
   const size_t piece = std::min(STAGE_BYTES, std::max<size_t>(bytes, 4096));
+  char *pin = (char *)pinned_buf(7, 2 * piece);
+  if (!pin) { set_error("pinned staging buffer allocation failed"); return PSG_ENOMEM; }
   hipEvent_t ev[2] = {event_acquire(), event_acquire()};
   bool used[2] = {false, false};
   int rc = 0;
@@ -263,7 +280,7 @@ int copy_h2d(void *d, const void *h, size_t bytes) {
     const int s = (int)(k & 1);
     const size_t n = std::min(piece, bytes - off);
     if (used[s] && wait_event_poll(ev[s]) != hipSuccess) { set_error("copy_h2d: device error"); rc = PSG_EDEVICE; break; }
-    memcpy(pin + s * piece, (const char *)h + off, n);
+    host_copy(pin + s * piece, (const char *)h + off, n);
     if (hipMemcpyAsync((char *)d + off, pin + s * piece, n, hipMemcpyHostToDevice, stream()) != hipSuccess ||
         hipEventRecord(ev[s], stream()) != hipSuccess) { set_error("copy_h2d: hipMemcpyAsync failed"); rc = PSG_EDEVICE; break; }
     used[s] = true;
@@ -296,7 +313,7 @@ int copy_d2h(void *h, const void *d, size_t bytes) {
       const int s = (int)((k - 1) & 1);
       const size_t off = (k - 1) * piece, n = std::min(piece, bytes - off);
       if (wait_event_poll(ev[s]) != hipSuccess) { set_error("copy_d2h: device error"); rc = PSG_EDEVICE; break; }
-      memcpy((char *)h + off, pin + s * piece, n);
+      host_copy((char *)h + off, pin + s * piece, n);
     }
   }
   hipError_t e = sync_stream();

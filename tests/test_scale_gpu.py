@@ -190,9 +190,10 @@ def test_bench_configs2_shape_reduced(gpu_lib):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gib", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
-                        "--with-output-d2h"], capture_output=True, text=True, timeout=900)
+                        "--with-output-d2h", "--psa-hbm-gib", "6"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["blocks"] == 8 and d["config"]["half_blocks"] == 16 and d["value"] > 0
-    assert d["pcie"]["h2d_bytes_per_step"] == 4 * (4 << 30) and d["with_output_d2h"]["entries_received_on_host"] == 4 << 30
+    # 6 GiB of the 16 GiB of partial SAs are resident in HBM (5 half-blocks of 1 GiB + margin), the rest streams in
+    assert 0 < d["pcie"]["h2d_bytes_per_step"] < 4 * (4 << 30) and d["with_output_d2h"]["entries_received_on_host"] == 4 << 30
     assert d["roofline"]["frac"] > 0.05 and d["streamed_suffixes_per_step"] > 15 * (1 << 30)
