@@ -504,12 +504,14 @@ def config2(args, ctx, n, block):
             budget -= 4 * v["size"] + (1 << 20)
             resident += 1
         log(f"{resident} of {len(prepared)} partial SAs resident in HBM ({sum(4 * v['size'] for v in prepared.values() if v['psa_host'] is None) / 2 ** 30:.1f} GiB), the rest in pinned host memory")
-    for _ in range(warm):
-        step(False)
+    for k in range(warm):
+        dt = step(False)
+        log(f"warm-up step {k + 1}/{warm}: {dt:.2f}s")
     api.sync()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        dt = step(True)
+        log(f"step {k + 1}/{args.steps}: {dt:.2f}s")          # a progress line per step (a step takes several seconds)
     api.sync()
     elapsed = time.perf_counter() - t_start
     K = args.steps
