@@ -16,6 +16,11 @@
 //                                 cores, and that is the default): sort the half-blocks on the device with the
 //                                 bench's prefix-key sorter (psascan_amd_extras.h; texts whose repeats stay below a
 //                                 few hundred symbols -- anything else falls back to the host sorter)
+//                --text-on-host [--tail-chunk N]
+//                                 the text stays in host memory (automatic beyond 55 % of the device memory): every
+//                                 pass uploads its tail in chunks of N symbols (default 1 Gi) and streams them one
+//                                 after the other with the exact hand-over rank -- stream.hpp:104-106 reads the tail
+//                                 from the text file the same way
 //                --spill-psa      keep the partial suffix arrays in part files next to GAPFILE (-g; default: the
 //                                 output name) instead of host memory: `GAPFILE.psa.<beg>` is written when a block
 //                                 is done and mapped back for the merge (the reference's distributed_file,
@@ -88,7 +93,9 @@ static void usage(int status) {
          "      --fanout=F          sub-ranges merged per step of that merging (default 4)\n"
          "      --no-device-merge   sort every half-block in one piece on the host (extension)\n"
          "      --device-sort       suffix-sort the half-blocks on the device (extension; the default keeps\n"
-         "                          the sort on the host cores like the reference)\n",
+         "                          the sort on the host cores like the reference)\n"
+         "      --text-on-host      keep the text in host memory and upload the tail of every pass in chunks\n"
+         "                          (automatic for texts beyond 55%% of the device memory); --tail-chunk=N\n",
          program_name);
   std::exit(status);
 }
@@ -210,11 +217,13 @@ static void log_phase(const char *what, double t0, int64_t units = 0) {
 struct Options {
   int64_t forced_block = 0, max_chains = 0, check_samples = -1, leaf_size = 0;
   int fanout = 4;
-  bool discard = false, spill_psa = false, hierarchical = true, device_sort = false;
+  int64_t tail_chunk = (int64_t)1 << 30;
+  bool discard = false, spill_psa = false, hierarchical = true, device_sort = false, text_on_host = false;
   std::string gap_prefix;
 };
 
-static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt) {
+static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt_in) {
+  Options opt = opt_in;   // adjusted below when the text stays in host memory
   const int64_t forced_block = opt.forced_block, max_chains = opt.max_chains;
   // ---- planner: psascan.hpp:57-91 ----
   if (ram_use < 6) throw std::runtime_error("not enough memory to run pSAscan.");
@@ -247,7 +256,20 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   char devname[256];
   CK(psg_device_name(devname, sizeof devname));
   fprintf(stderr, "Device = %s\n\n", devname);
-  Dev d_text = upload(text.data(), n);
+  // ---- where the text lives on the device.  Default: all of it in HBM (1 byte per symbol next to ~45 bytes per block
+  // symbol of temporaries).  A text that would take more than 55 % of the device (or --text-on-host) stays in host
+  // memory: every pass then uploads its tail in chunks and streams chunk after chunk with the exact hand-over rank
+  // (the reference reads the tail from the text file in every pass, stream.hpp:104-106).
+  int64_t dev_free = 0, dev_total = 0;
+  CK(psg_device_memory(&dev_free, &dev_total));
+  const bool text_on_host = opt_in.text_on_host || (double)n > 0.55 * (double)dev_total;
+  if (text_on_host) {
+    if (opt_in.check_samples >= 0) throw std::runtime_error("--check needs the text in HBM (not with --text-on-host / a text beyond 55 % of the device memory)");
+    opt.hierarchical = false; opt.device_sort = false;   // the device-side sorters read the text beyond a half-block's end
+    fprintf(stderr, "Text stays in host memory: tails are uploaded in chunks of %ld symbols\n\n", (long)opt_in.tail_chunk);
+  }
+  Dev d_text = text_on_host ? Dev(16) : upload(text.data(), n);
+  Dev tail_buf(text_on_host ? opt.tail_chunk + 64 : 16);
   const int64_t gt_words = (n + 31) / 32 + 2;
   Dev gt_cur(4 * gt_words, true), gt_new(4 * gt_words, true);
   std::vector<DoneHalfBlock> hbs;
@@ -264,6 +286,28 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
                          uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
                          psg_stream_stats *st) {
+    if (text_on_host) {
+      // the tail in chunks, right to left; u = distance from the tail end (chunk bounds are multiples of 64, so the gt
+      // words of a chunk start on a word boundary); every chunk starts from the rank the previous one ended with
+      const int64_t C = std::max<int64_t>(64, opt.tail_chunk / 64 * 64);
+      psg_stream_stats acc{};
+      int64_t fin = rank_at_end;
+      for (int64_t u_lo = 0; u_lo < T || (T == 0 && u_lo == 0); u_lo += C) {
+        const int64_t u_hi = std::min(T, u_lo + C), len = u_hi - u_lo, pos = tail_beg + (T - u_hi);
+        if (len > 0) CK(psg_h2d(tail_buf.p, text.data() + pos, len));
+        psg_stream_args a{};
+        a.rank = rank; a.block_i0 = i0; a.block_last_symbol = last_sym; a.d_tail = tail_buf.as<uint8_t>(); a.tail_len = len; a.right_context = 0;
+        a.d_gt_in = d_gt_in ? d_gt_in + (u_lo >> 5) : nullptr; a.rank_at_context_end = fin; a.d_gap = d_gap; a.d_gt_out = d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr;
+        a.max_chains = max_chains; a.flags = u_lo == 0 ? PSG_GAP_UNINITIALIZED : 0; a.search = nullptr; a.tail_begin_abs = pos;
+        psg_stream_stats s1{};
+        if (psg_stream_gap_args(&a, &fin, &s1)) throw std::runtime_error(std::string("psg_stream_gap_args (tail chunk): ") + psg_last_error());
+        acc.n_chains = std::max(acc.n_chains, s1.n_chains); acc.chain_len = s1.chain_len; acc.warmup_steps = std::max(acc.warmup_steps, s1.warmup_steps);
+        acc.unresolved += s1.unresolved; acc.rounds += s1.rounds; acc.kernel_ms += s1.kernel_ms; acc.total_ms += s1.total_ms; acc.hist_ms += s1.hist_ms;
+        if (T == 0) break;
+      }
+      *st = acc;
+      return;
+    }
     psg_stream_args a{};
     a.rank = rank; a.block_i0 = i0; a.block_last_symbol = last_sym; a.d_tail = d_text.as<uint8_t>() + tail_beg; a.tail_len = T; a.right_context = 0;
     a.d_gt_in = d_gt_in; a.rank_at_context_end = rank_at_end; a.d_gap = d_gap; a.d_gt_out = d_gt_out; a.max_chains = max_chains;
@@ -694,7 +738,8 @@ int main(int argc, char **argv) {
                                          {"check", optional_argument, NULL, 1002}, {"discard-output", no_argument, NULL, 1003},
                                          {"spill-psa", no_argument, NULL, 1004}, {"leaf-size", required_argument, NULL, 1005},
                                          {"fanout", required_argument, NULL, 1006}, {"no-device-merge", no_argument, NULL, 1007},
-                                         {"device-sort", no_argument, NULL, 1008}, {NULL, 0, NULL, 0}};
+                                         {"device-sort", no_argument, NULL, 1008}, {"text-on-host", no_argument, NULL, 1009},
+                                         {"tail-chunk", required_argument, NULL, 1010}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
   Options opt;
@@ -718,6 +763,8 @@ int main(int argc, char **argv) {
       case 1006: opt.fanout = atoi(optarg); break;
       case 1007: opt.hierarchical = false; break;
       case 1008: opt.device_sort = true; break;
+      case 1009: opt.text_on_host = true; break;
+      case 1010: { uint64_t v; if (!parse_number(optarg, &v) || v < 64) { fprintf(stderr, "Error: bad --tail-chunk\n\n"); usage(EXIT_FAILURE); } opt.tail_chunk = (int64_t)v; break; }
       default: usage(EXIT_FAILURE); break;
     }
   }

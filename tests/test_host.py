@@ -383,3 +383,26 @@ def test_cli_device_sort_extension(tmp_path):
                 assert ("device sufsort" in r.stderr) and (("gave up" in r.stderr) == (name == "per"))
         assert outs[0] == outs[1]
         assert np.array_equal(orc.sa5_to_sa(np.frombuffer(outs[0], np.uint8)), orc.suffix_array(t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rand", "sig3", "per3"])
+def test_cli_text_on_host_chunked_tails(tmp_path, kind):
+    """--text-on-host: the text is never resident in HBM; every pass uploads its tail in chunks (here 4096 symbols) and
+    streams them one after the other with the exact hand-over rank (stream.hpp:104-106 reads the tail from the file per
+    pass).  Same suffix array as the oracle's."""
+    rng = np.random.default_rng(3)
+    n = 90_001
+    t = {"rand": lambda: rng.integers(0, 255, n, dtype=np.uint8), "sig3": lambda: rng.integers(0, 3, n, dtype=np.uint8),
+         "per3": lambda: np.frombuffer((b"abc" * (n // 3 + 1))[:n], np.uint8).copy()}[kind]()
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    out = tmp_path / "x.sa5"
+    r = subprocess.run([CLI, "-m", "1G", "--block-size", "20000", "--text-on-host", "--tail-chunk", "4096", "-v", "-o", str(out), str(f)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Text stays in host memory" in r.stderr
+    assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
+    r = subprocess.run([CLI, "-m", "1G", "--text-on-host", "--check", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert r.returncode == 1 and "--check needs the text in HBM" in r.stderr
