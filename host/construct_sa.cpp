@@ -534,6 +534,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     H.beg = hb; H.size = he - hb;
     const double t0 = wclock();
     if (opt.device_sort && H.size < ((int64_t)1 << 32)) {
+      // same input restriction as the host sorter and the reference (initial_partial_sufsort.hpp:141-146)
+      if (memchr(text.data() + hb, 255, (size_t)H.size)) throw std::runtime_error("the input contains byte 255");
       Dev psa(4 * H.size + 16), bwt(H.size + 16), gt(4 * ((H.size + 31) / 32 + 2), true);
       int64_t i0 = -1, ties = 0;
       if (psgx_sort_halfblock(d_text.as<uint8_t>(), n, hb, he, psa.as<uint32_t>(), bwt.as<uint8_t>(), &i0, gt.as<uint32_t>(), &ties) == 0) {

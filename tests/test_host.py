@@ -406,3 +406,29 @@ def test_cli_text_on_host_chunked_tails(tmp_path, kind):
     r = subprocess.run([CLI, "-m", "1G", "--text-on-host", "--check", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert r.returncode == 1 and "--check needs the text in HBM" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_edge_inputs(tmp_path):
+    """the reference's input constraints and degenerate sizes: byte 255 is fatal (initial_partial_sufsort.hpp:141-146:
+    exit status 1, no output left behind), an empty file gives an empty .sa5, one- and two-symbol files work"""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    f = tmp_path / "bad.bin"
+    f.write_bytes(bytes([1, 2, 3, 255, 4, 5, 6, 7] * 1000))
+    for extra in ([], ["--device-sort"], ["--no-device-merge"]):
+        r = subprocess.run([CLI, "-m", "1G", "--block-size", "3000", str(f)] + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 1 and "255" in r.stderr, r.stderr[-500:]
+        assert not (tmp_path / "bad.bin.sa5").exists()
+    e = tmp_path / "empty.bin"
+    e.write_bytes(b"")
+    r = subprocess.run([CLI, "-m", "1G", str(e)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and (tmp_path / "empty.bin.sa5").read_bytes() == b""
+    for data in (b"a", b"ab", b"ba", b"aa", b"\x00", b"\x00\x00\x01"):
+        g = tmp_path / "tiny.bin"
+        g.write_bytes(data)
+        if (tmp_path / "tiny.bin.sa5").exists():
+            os.remove(tmp_path / "tiny.bin.sa5")
+        r = subprocess.run([CLI, "-m", "1G", str(g)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-500:]
+        got = orc.sa5_to_sa(np.frombuffer((tmp_path / "tiny.bin.sa5").read_bytes(), np.uint8))
+        assert np.array_equal(got, orc.suffix_array(np.frombuffer(data, np.uint8)))
