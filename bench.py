@@ -596,7 +596,9 @@ def config_blocks(args, ctx, block):
     def replay(text, hb, he, gt_tail):
         r = prepared[(hb, he)]
         return {"device": True, "psa_lo": r["psa_lo"], "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb}
-    comm = "cuda" if os.environ.get("PSASCAN_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+    # tensors handed to the collectives: CUDA tensors with RCCL; CPU tensors in the gloo rehearsal (PSASCAN_COMM=cuda
+    # rehearses the CUDA-tensor code path over gloo)
+    comm = os.environ.get("PSASCAN_COMM") or ("cuda" if os.environ.get("PSASCAN_DIST_BACKEND", "nccl") == "nccl" else "cpu")
     ops = BD.HipBlockOps(torch, api, d_text, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True)
     agg = {"suffixes": 0, "kernel_ms": 0.0, "stream_ms": 0.0, "launches": 0}
 
