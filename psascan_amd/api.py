@@ -272,6 +272,20 @@ class MergePlan:
             pass
 
 
+def merge_run_u32(plan, out_begin, out_count, d_out):
+    """merged order as u32 values (plan levels' beg relative to the enclosing range)"""
+    check(lib().psg_merge_run_u32(plan.h, out_begin, out_count, _ptr(d_out)))
+
+
+def halfblock_from_psa(sc, beg, size, d_psa, want_gt=True):
+    """-> (d_bwt, i0, d_gt_begin): BWT (dummy 0 at i0), i0 and gt_begin of text[beg..beg+size) from its partial SA"""
+    d_bwt = DeviceBuffer(size + 16)
+    d_gt = zeros(4 * ((size + 31) // 32 + 2)) if want_gt else None
+    i0 = C.c_int64(-1)
+    check(lib().psg_halfblock_from_psa(C.byref(sc), beg, size, _ptr(d_psa), d_bwt.ptr, C.byref(i0), _ptr(d_gt)))
+    return d_bwt, i0.value, d_gt
+
+
 def bits_rank1(d_bits, nbits, positions):
     """ones in d_bits[0 .. pos) for every pos (rank1 of ranksel_support.hpp:45-187)"""
     pos = np.ascontiguousarray(positions, np.int64)

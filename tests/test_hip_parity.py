@@ -460,6 +460,59 @@ def test_stream_gap_repetitive_text_resolves_in_one_round(A, monkeypatch, kind, 
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+# ------------------------------------------------------------------ in-memory pSAscan pieces (leaves merged on the device)
+@pytest.mark.parametrize("kind", ["rand255", "sig4z", "alla", "fib", "per3"])
+def test_subranges_merged_into_a_partial_sa(A, kind):
+    """inmem_psascan.hpp:64-304 with the hot path as the merger: the partial SAs of consecutive sub-ranges (whole-text
+    order) + their gap arrays w.r.t. the sub-ranges to their right inside the range -> psg_merge_run_u32 gives the
+    range's partial SA, psg_halfblock_from_psa its BWT / i0 / gt_begin -- all equal to the oracle's for the range."""
+    n = 8000
+    t = make_text(kind, n, 6)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = 700, 6100
+    cuts = [b, 1900, 1901, 3300, 4800, e]
+    hbs = []
+    for h in range(len(cuts) - 1):
+        x0, x1 = cuts[h], cuts[h + 1]
+        psa, _, _, _ = orc.partial_sa(t, sa, isa, x0, x1, want_gt=False)
+        mbv = None
+        if x1 < e:
+            ranks = np.searchsorted(np.sort(isa[x0:x1]), isa[x1:e])          # gap w.r.t. the rest of the RANGE only
+            g = np.bincount(ranks, minlength=x1 - x0 + 1).astype(np.uint64)
+            bv, nb = orc.gap_to_bitvector(g, x1 - x0)
+            mbv = A.upload(bv[: (nb + 7) // 8])
+        hbs.append({"beg": x0 - b, "size": x1 - x0, "psa_lo": A.upload(psa.astype(np.uint32)), "psa_hi": None, "mbv": mbv})
+    plan = A.MergePlan(hbs)
+    d_psa = A.DeviceBuffer(4 * (e - b) + 16)
+    A.merge_run_u32(plan, 0, e - b, d_psa)
+    want_psa, want_bwt, want_i0, want_gt = orc.partial_sa(t, sa, isa, b, e)
+    assert np.array_equal(A.download(d_psa, np.uint32, e - b).astype(np.int64), want_psa)
+    d_text = A.upload(t, pad_to=16)
+    sc = A.search_ctx(d_text, n, n, None, [])            # comparisons read on in the text
+    d_bwt, i0, d_gt = A.halfblock_from_psa(sc, b, e - b, d_psa)
+    assert i0 == want_i0 and np.array_equal(A.download(d_bwt, np.uint8, e - b), want_bwt)
+    assert np.array_equal(orc.bits(A.download(d_gt, np.uint8, (e - b + 7) // 8), e - b), orc.bits(want_gt, e - b))
+
+
+def test_bits_rank1_and_memory_queries(A):
+    rng = np.random.default_rng(3)
+    nbits = 300_007
+    bits = (rng.random(nbits) < 0.3).astype(np.uint8)
+    d = A.upload(np.concatenate([np.packbits(bits, bitorder="little"), np.zeros(8, np.uint8)]), pad_to=8)
+    pos = np.concatenate([[0, 1, 31, 32, 4095, 4096, 4097, nbits - 1, nbits], rng.integers(0, nbits + 1, 500)]).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(bits.astype(np.int64))])
+    assert np.array_equal(A.bits_rank1(d, nbits, pos), cs[pos])
+    in_use, peak, reserved = A.mem_stats()
+    free, total = A.device_memory()
+    assert 0 < in_use <= peak <= reserved <= total and free <= total
+    pa = A.PinnedArray(1 << 20, np.uint32)
+    pa.array[:] = np.arange(1 << 20, dtype=np.uint32)
+    buf = A.upload(pa.array)                              # pinned source: one DMA, no staging
+    assert np.array_equal(A.download(buf, np.uint32, 1 << 20), pa.array)
+    pa.free()
+
+
 def test_device_allocator_arena(A, gpu_lib):
     """psg_malloc/psg_free go through the arena of runtime.hip (best fit, split, coalesce for blocks >= 1 MiB,
     size classes below): live blocks never overlap, whatever the order of frees and the mix of sizes."""
