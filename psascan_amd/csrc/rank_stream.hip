@@ -1138,7 +1138,19 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     // back with one) two attempts suffice: a search costs about as much as a few hundred warm-up steps
     const int attempts = (A.search || A.fail_if_unresolved) ? 2 : 4;
     nun = 0;
-    for (int attempt = 0; attempt < attempts; ++attempt) {
+    // A small pass with a search context skips the warm-up: W warm-up steps per chain would cost more than the pass
+    // itself (K = 49 152 chains of 128 steps for a 6 Mi tail: 512 warm-up steps each), a string search per start does
+    // not.  Chain 0 starts from the exact rank at the tail end.
+    const bool search_all = A.search && K <= ((i64)1 << 17) && ctx == 0 && rank_at_end >= 0;
+    if (search_all) {
+      list.clear();
+      lo[0] = hi[0] = rank_at_end; resolved[0] = 1;
+      for (i64 k = 1; k < K; ++k) { lo[k] = 0; hi[k] = r->m; resolved[k] = 0; list.push_back(k); }
+      nun = (i64)list.size();
+      st.warmup_steps = 0;
+      if (nun == 0) PSG_HIP(hipMemcpyAsync(lo_d.p, lo, K * 8, hipMemcpyHostToDevice, stream()));   // a single chain: its start is all there is
+    }
+    for (int attempt = 0; attempt < attempts && !search_all; ++attempt) {
       DISPATCH_LAYOUT(r, launch_warm, r, WP);
       PSG_HIP(hipGetLastError());
       PSG_HIP(hipMemcpyAsync(lo, lo_d.p, K * 8, hipMemcpyDeviceToHost, stream()));
@@ -1155,6 +1167,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
       if (int rc_ = psg::copy_h2d(list_d.p, list.data(), (size_t)(nun * 8))) return rc_;
       PSG_HIP(psg::sync_stream());
     }
+    if (search_all) break;
     const i64 few = 16384;
     if (plan == 0 && A.max_chains <= 0 && nun > K / 4 && K > few) { Ktarget = few; continue; }
     break;
