@@ -178,6 +178,10 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   uint8_t code[256];
   int sigma = 0;
   for (int c = 0; c < 256; ++c) { code[c] = 0; if (present[c]) code[c] = (uint8_t)(++sigma); }   // 0 = past the end of the text
+  // the refinement reads keys further right than `reach`: a symbol that does not occur in or near the block has no
+  // code (equal keys must mean equal symbols) -- the sorter gives up on such a key and SA-IS takes over
+  uint8_t code_all[256];
+  for (int c = 0; c < 256; ++c) code_all[c] = present[c] ? code[c] : 0xFF;
   if (present[255]) throw std::runtime_error("the input contains byte 255");
   int bits = 1;
   while ((1 << bits) <= sigma) ++bits;
@@ -191,28 +195,10 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   const double info = sigma >= 2 ? std::log2((double)sigma) / bits : 1.0;
   int need = std::min(used, (int)std::ceil((lg + 8) / info));
   if (need > 32 && (int)std::ceil((lg + 5) / info) <= 32) need = 32;   // the packed 32-bit path below; groups a little larger
-  // Is this text for the prefix-key sorter at all?  4096 evenly spaced suffixes: if more than a few of them share their
-  // whole sort key with another sample, every suffix shares it with many (natural language: ~20 per key at 2 MiB), the
-  // group sorts dominate and SA-IS is twice as fast -- decided before the radix passes are paid for.
-  if (m >= (1 << 16)) {
-    const int S = 4096;
-    std::vector<uint64_t> sk((size_t)S);
-    for (int q = 0; q < S; ++q) {
-      const int64_t i = beg + (m / S) * q;
-      uint64_t k = 0;
-      for (int t = 0; t < per_key; ++t) k = (k << bits) | (i + t < n ? code[text[i + t]] : 0);
-      sk[(size_t)q] = need >= 64 ? k : ((k << (64 - used)) >> (64 - need));
-    }
-    std::sort(sk.begin(), sk.end());
-    int ties = 0;
-    for (int q = 1; q < S; ++q) ties += sk[(size_t)q] == sk[(size_t)q - 1];
-    if (ties > S / 128) return false;
-  }
   std::vector<uint32_t> idx((size_t)m);
-  // total symbol comparisons allowed before SA-IS is the better tool: text with repeats of tens of symbols (natural
-  // language) spends ~50 comparisons per suffix in the group sorts and runs at half of SA-IS's speed, random text
-  // needs about one -- so the budget is small and the sorter gives up early
-  int64_t budget = 12 * m + (1 << 16);
+  // work allowed in the group phase before SA-IS is the better tool (4 units per suffix and refinement round, 1 per
+  // symbol comparison): natural language needs 3-4 rounds, random text none; periodic text runs out and gives up
+  int64_t budget = 24 * m + (1 << 16);
   // text[beg+a ..n) < text[beg+b ..n) for two suffixes known to agree on their first `known` symbols
   auto less_from = [&](uint32_t a, uint32_t b, int known) {
     int64_t x = beg + a + known, y = beg + b + known;
@@ -250,12 +236,43 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
       }
       std::vector<uint64_t>().swap(kv2);
       const int gs = 64 - need, known = need / bits;   // a group = equal sorted bits = `known` whole symbols (at least)
+      // Groups of equal prefixes are refined with the NEXT per_key symbols as an integer key (read straight from the
+      // text), group by group and deeper and deeper -- natural language leaves ~20 suffixes per 12-symbol prefix and
+      // needs 3-4 such rounds; comparing suffix pairs symbol by symbol instead made this sorter slower than SA-IS there.
+      std::vector<std::pair<uint64_t, uint32_t>> tmp;
+      auto key_at = [&](int64_t p) {
+        uint64_t k = 0;
+        for (int t = 0; t < per_key; ++t) {
+          const uint8_t cd = p + t < n ? code_all[text[p + t]] : 0;
+          if (cd == 0xFF) throw GtCapExceeded();
+          k = (k << bits) | cd;
+        }
+        return k;
+      };
+      std::vector<std::pair<std::pair<int64_t, int64_t>, int64_t>> stack;   // ((lo, hi), depth): kv[lo..hi) share `depth` symbols
       for (int64_t g0 = 0; g0 < m;) {
         int64_t g1 = g0 + 1;
         while (g1 < m && (kv[(size_t)g1] >> gs) == (kv[(size_t)g0] >> gs)) ++g1;
-        if (g1 - g0 > 1) {
-          if (g1 - g0 > (1 << 16)) return false;
-          std::sort(kv.begin() + g0, kv.begin() + g1, [&](uint64_t a, uint64_t b) { return less_from((uint32_t)a, (uint32_t)b, known); });
+        if (g1 - g0 > 1) stack.push_back({{g0, g1}, known});
+        while (!stack.empty()) {
+          const int64_t lo = stack.back().first.first, hi = stack.back().first.second, depth = stack.back().second;
+          stack.pop_back();
+          const int64_t cnt = hi - lo;
+          if (cnt <= 12) {
+            std::sort(kv.begin() + lo, kv.begin() + hi, [&](uint64_t a, uint64_t b) { return less_from((uint32_t)a, (uint32_t)b, (int)std::min<int64_t>(depth, 1 << 30)); });
+            continue;
+          }
+          if (depth >= cap || (budget -= 4 * cnt) < 0) throw GtCapExceeded();
+          tmp.resize((size_t)cnt);
+          for (int64_t i = 0; i < cnt; ++i) { const uint32_t p = (uint32_t)kv[(size_t)(lo + i)]; tmp[(size_t)i] = {key_at(beg + (int64_t)p + depth), p}; }
+          std::sort(tmp.begin(), tmp.end());
+          for (int64_t i = 0; i < cnt; ++i) kv[(size_t)(lo + i)] = (kv[(size_t)lo] & 0xFFFFFFFF00000000ull) | tmp[(size_t)i].second;
+          for (int64_t r0 = 0; r0 < cnt;) {
+            int64_t r1 = r0 + 1;
+            while (r1 < cnt && tmp[(size_t)r1].first == tmp[(size_t)r0].first) ++r1;
+            if (r1 - r0 > 1) stack.push_back({{lo + r0, lo + r1}, depth + per_key});
+            r0 = r1;
+          }
         }
         g0 = g1;
       }
