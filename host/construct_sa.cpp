@@ -479,7 +479,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       psg_stream_args a{};
       a.rank = rk; a.block_i0 = c.i0; a.block_last_symbol = text.p[(size_t)x1 - 1]; a.d_tail = d_text.as<uint8_t>() + x1; a.tail_len = T; a.right_context = 0;
       a.d_gt_in = gt_c.as<uint32_t>(); a.rank_at_context_end = r_end; a.d_gap = gap.as<uint32_t>(); a.d_gt_out = gt_n.as<uint32_t>(); a.max_chains = max_chains;
-      a.flags = PSG_GAP_UNINITIALIZED; a.search = &sc; a.tail_begin_abs = x1;
+      a.flags = PSG_GAP_UNINITIALIZED | PSG_SEARCH_ALL_STARTS; a.search = &sc; a.tail_begin_abs = x1;   // leaves sorted with a bounded look-ahead: no long repeats here
       psg_stream_stats st;
       if (psg_stream_gap_args(&a, nullptr, &st)) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
       psg_rank_free(rk);

@@ -169,6 +169,10 @@ int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_positions, int6
  * unresolved chains one after another when no search context is given: the caller uploads the partial SAs and
  * calls again).                                                                                               */
 #define PSG_FAIL_IF_UNRESOLVED 2
+/* with `search`: find EVERY chain start of a small pass (at most 2^17 chains) by string search and skip the warm-up --
+ * for callers that know the text has no long repeats around here (construct_sa's leaf merging: the leaves were sorted
+ * with a bounded look-ahead); on periodic text every search costs a block length of comparisons                    */
+#define PSG_SEARCH_ALL_STARTS 4
 #define PSG_EUNRESOLVED (-6)
 typedef struct {
   const psg_rank_t *rank;

@@ -141,7 +141,7 @@ def initial_ranks(sc, positions):
 
 
 def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, rank_at_tail_end, d_gap, d_gt_out,
-               max_chains=0, right_context=0, fresh_gap=False, search=None, tail_begin_abs=0, fail_if_unresolved=False):
+               max_chains=0, right_context=0, fresh_gap=False, search=None, tail_begin_abs=0, fail_if_unresolved=False, search_all=False):
     """One streaming pass (compute_gap<T>), optionally over a sub-range of the tail with
     `right_context` bytes/bits of valid text/gt to its right.  fresh_gap: d_gap is uninitialised
     (the reference's freshly constructed gap array) -- the pass zero-fills / overwrites it.
@@ -151,7 +151,7 @@ def stream_gap(rank, block_i0, block_last_symbol, d_tail, tail_len, d_gt_in, ran
     st = StreamStatsC()
     if search is not None or fail_if_unresolved:
         a = StreamArgsC(rank.h, block_i0, int(block_last_symbol), _ptr(d_tail), tail_len, right_context, _ptr(d_gt_in), rank_at_tail_end,
-                        _ptr(d_gap), _ptr(d_gt_out), max_chains, (1 if fresh_gap else 0) | (2 if fail_if_unresolved else 0),
+                        _ptr(d_gap), _ptr(d_gt_out), max_chains, (1 if fresh_gap else 0) | (2 if fail_if_unresolved else 0) | (4 if search_all else 0),
                         C.pointer(search) if search is not None else None, tail_begin_abs)
         check(lib().psg_stream_gap_args(C.byref(a), C.byref(fin), C.byref(st)))
         return fin.value, StreamStats(st)

@@ -966,6 +966,7 @@ struct PassArgs {
   i64 max_chains;
   bool fresh;                     // PSG_GAP_UNINITIALIZED
   bool fail_if_unresolved;        // PSG_FAIL_IF_UNRESOLVED
+  bool search_all;                // PSG_SEARCH_ALL_STARTS
   const psg_search_ctx *search;   // K8 for chain starts the warm-up leaves open
   i64 tail_begin_abs;
   u32 **log_out;
@@ -984,7 +985,7 @@ extern "C" int psg_stream_gap_ctx(const psg_rank_t *r, int64_t i0, int last_sym,
                                   int64_t ctx, const uint32_t *d_gt_in, int64_t rank_at_end, uint32_t *d_gap,
                                   uint32_t *d_gt_out, int64_t max_chains, int64_t *h_final_rank, psg_stream_stats *stats) {
   PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
-  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, false, false, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
+  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, false, false, false, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
 }
 // the gap array is uninitialised on entry (PSG_GAP_UNINITIALIZED): zero-filled or overwritten by the pass
 extern "C" int psg_stream_gap_ex(const psg_rank_t *r, int64_t i0, int last_sym, const uint8_t *d_tail, int64_t T,
@@ -993,16 +994,16 @@ extern "C" int psg_stream_gap_ex(const psg_rank_t *r, int64_t i0, int last_sym, 
   PSG_REQUIRE(d_gap, "psg_stream_gap: gap array required");
   PSG_REQUIRE((flags & ~(PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED)) == 0, "psg_stream_gap_ex: unknown flag");
   return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, d_gap, d_gt_out, max_chains, (flags & PSG_GAP_UNINITIALIZED) != 0,
-                              (flags & PSG_FAIL_IF_UNRESOLVED) != 0, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
+                              (flags & PSG_FAIL_IF_UNRESOLVED) != 0, false, nullptr, 0, nullptr, nullptr}, h_final_rank, stats);
 }
 extern "C" int psg_stream_gap_args(const psg_stream_args *a, int64_t *h_final_rank, psg_stream_stats *stats) {
   PSG_REQUIRE(a && a->d_gap, "psg_stream_gap_args: arguments and gap array required");
-  PSG_REQUIRE((a->flags & ~(PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED)) == 0, "psg_stream_gap_args: unknown flag");
+  PSG_REQUIRE((a->flags & ~(PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED | PSG_SEARCH_ALL_STARTS)) == 0, "psg_stream_gap_args: unknown flag");
   PSG_REQUIRE(!a->search || (a->tail_begin_abs >= 0 && a->tail_begin_abs + a->tail_len + a->right_context <= a->search->n),
               "psg_stream_gap_args: the tail lies outside the text of the search context");
   return stream_impl(PassArgs{a->rank, a->block_i0, a->block_last_symbol, a->d_tail, a->tail_len, a->right_context, a->d_gt_in, a->rank_at_context_end,
                               a->d_gap, a->d_gt_out, a->max_chains, (a->flags & PSG_GAP_UNINITIALIZED) != 0, (a->flags & PSG_FAIL_IF_UNRESOLVED) != 0,
-                              a->search, a->tail_begin_abs, nullptr, nullptr}, h_final_rank, stats);
+                              (a->flags & PSG_SEARCH_ALL_STARTS) != 0 && a->search != nullptr, a->search, a->tail_begin_abs, nullptr, nullptr}, h_final_rank, stats);
 }
 
 // same pass, but the ranks are handed back as a log (one u32 per streamed suffix, 0xFFFFFFFF =
@@ -1015,7 +1016,7 @@ extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym,
   PSG_REQUIRE(d_log && nlog, "psg_stream_gap_log: output pointers required");
   PSG_REQUIRE(r && r->m < 0xFFFFFFFFll, "psg_stream_gap_log: block too large for a 32-bit rank log");
   *d_log = nullptr; *nlog = 0;
-  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, false, false, nullptr, 0, d_log, nlog}, h_final_rank, stats);
+  return stream_impl(PassArgs{r, i0, last_sym, d_tail, T, ctx, d_gt_in, rank_at_end, nullptr, d_gt_out, max_chains, false, false, false, nullptr, 0, d_log, nlog}, h_final_rank, stats);
 }
 
 // A pass over a long tail is cut into chunks of at most 2^31 suffixes, streamed right to left with
@@ -1141,7 +1142,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     // A small pass with a search context skips the warm-up: W warm-up steps per chain would cost more than the pass
     // itself (K = 49 152 chains of 128 steps for a 6 Mi tail: 512 warm-up steps each), a string search per start does
     // not.  Chain 0 starts from the exact rank at the tail end.
-    const bool search_all = A.search && K <= ((i64)1 << 17) && ctx == 0 && rank_at_end >= 0;
+    const bool search_all = A.search_all && A.search && K <= ((i64)1 << 17) && ctx == 0 && rank_at_end >= 0;
     if (search_all) {
       list.clear();
       lo[0] = hi[0] = rank_at_end; resolved[0] = 1;

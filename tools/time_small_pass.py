@@ -30,7 +30,7 @@ timeit("psg_rank_build", build)
 gap = api.gap_array(leaf, fill=None)
 st = [None]
 def stream():
-    _, st[0] = api.stream_gap(rk[0], r["i0"], last, d_text.at(leaf), T, gt_in, init, gap, gt_out, 0, fresh_gap=True, search=sc, tail_begin_abs=leaf)
+    _, st[0] = api.stream_gap(rk[0], r["i0"], last, d_text.at(leaf), T, gt_in, init, gap, gt_out, 0, fresh_gap=True, search=sc, tail_begin_abs=leaf, search_all=True)
 timeit(f"psg_stream_gap_args ({T >> 20} Mi suffixes)", stream)
 print("   stats:", st[0])
 bv = api.zeros(4 * ((leaf + T) // 32 + 4))
