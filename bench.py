@@ -504,6 +504,9 @@ def config2(args, ctx, n, block):
             budget -= 4 * v["size"] + (1 << 20)
             resident += 1
         log(f"{resident} of {len(prepared)} partial SAs resident in HBM ({sum(4 * v['size'] for v in prepared.values() if v['psa_host'] is None) / 2 ** 30:.1f} GiB), the rest in pinned host memory")
+        dt = step(False)              # the device arena was trimmed to place them: one untimed step lets it grow back
+        warm = max(0, warm - 1)
+        log(f"settling step: {dt:.2f}s")
     for k in range(warm):
         dt = step(False)
         log(f"warm-up step {k + 1}/{warm}: {dt:.2f}s")
