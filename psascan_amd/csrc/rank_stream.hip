@@ -451,7 +451,7 @@ template <int CNT, int B, int MODE, int CPL>
 // MODE 3 needs 82 VGPRs as the compiler allocates freely = 5 waves per SIMD (MODE 2: 76 = 6 waves); the kernel hides its
 // memory latency with resident chains, and 5 instead of 6 workgroups per CU cost 12 % per suffix at configs[2]: ask
 // for 6 (<= 80 VGPRs) there
-__global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 ? 6 : (B <= 64 ? PSG_STREAM_MIN_WAVES : 1))) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
+__global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WAVES < 6 ? 6 : (B <= 64 ? PSG_STREAM_MIN_WAVES : 1))) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
   extern __shared__ u64 lds[];
   __shared__ u32 lstage[MODE >= 2 ? CPL * 4 * PSG_WG : 1];
   __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
