@@ -357,7 +357,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       int64_t hb, he;
       half_range(2 * bid + side, hb, he);
       if (he <= hb) continue;
-      const int64_t nleaves = lookahead && opt.hierarchical ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
+      // (the merged partial SA holds 32-bit positions: a half-block of 2^32 symbols or more is sorted in one piece)
+      const int64_t nleaves = lookahead && opt.hierarchical && he - hb < ((int64_t)1 << 32) ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
       std::vector<int64_t> ids;
       for (int64_t k = nleaves - 1; k >= 0; --k) {           // rightmost leaf first
         const int64_t lb = hb + (he - hb) * k / nleaves, le = hb + (he - hb) * (k + 1) / nleaves;
