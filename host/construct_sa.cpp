@@ -140,7 +140,7 @@ struct Dev {  // owning device buffer
 // a finished half-block: the partial SA stays in host memory (or in a part file, --spill-psa), the merge bitvector in HBM
 struct DoneHalfBlock {
   int64_t beg = 0, size = 0;
-  std::vector<uint32_t> psa_lo;
+  psa_host::PsaVec psa_lo;
   std::vector<uint8_t> psa_hi;
   Dev mbv;
   std::string part_file;          // --spill-psa: [size x u32 low words][size x u8 high bytes, if any]
@@ -166,7 +166,7 @@ struct DoneHalfBlock {
     if (ok && part_has_hi) ok = fwrite(psa_hi.data(), 1, (size_t)size, f) == (size_t)size;
     if (f) ok = fclose(f) == 0 && ok;
     if (!ok) throw std::runtime_error("cannot write the part file " + part_file);
-    std::vector<uint32_t>().swap(psa_lo);
+    psa_host::PsaVec().swap(psa_lo);
     std::vector<uint8_t>().swap(psa_hi);
   }
   void map_back() {
@@ -282,7 +282,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // repeats some stay open: the pass then reports PSG_EUNRESOLVED, the partial SAs of the block's halves are
   // uploaded (they live in host memory) and the pass is repeated with a search context -- the open starts are
   // found by string search over them (em_compute_initial_ranks.hpp:222-319), still in one kernel launch.
-  struct PartRef { int64_t beg, size; const std::vector<uint32_t> *lo; const std::vector<uint8_t> *hi; };
+  struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const std::vector<uint8_t> *hi; };
   auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
                          uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
                          psg_stream_stats *st) {
@@ -525,7 +525,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   };
 
   // one half-block, ready for the block schedule: BWT and gt_begin in HBM, the partial SA in host memory
-  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; std::vector<uint32_t> psa_lo; std::vector<uint8_t> psa_hi; std::vector<uint32_t> gt_host; };
+  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; psa_host::PsaVec psa_lo; std::vector<uint8_t> psa_hi; std::vector<uint32_t> gt_host; };
   auto gt_host_of = [&](Half &h) -> const std::vector<uint32_t> & {   // gt_begin on the host (sequential sorter of the half to the left)
     if (h.gt_host.empty()) { h.gt_host.resize((size_t)((h.size + 31) / 32 + 1)); CK(psg_d2h(h.gt_host.data(), h.gt.p, 4 * (int64_t)h.gt_host.size())); }
     return h.gt_host;

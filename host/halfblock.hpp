@@ -23,9 +23,19 @@
 
 namespace psa_host {
 
+// resize() without zero-filling: a partial SA of 8 GiB is written once, in full, by the sorter or by a download from
+// the device -- value-initialising it first touches every page on one thread (1.3 s per 8 GiB)
+template <class T> struct default_init_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_alloc<U>; };
+  template <class U, class... A> void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+typedef std::vector<uint32_t, default_init_alloc<uint32_t>> PsaVec;
+
 struct HalfBlock {
   int64_t beg = 0, size = 0, i0 = 0;
-  std::vector<uint32_t> psa_lo;
+  PsaVec psa_lo;
   std::vector<uint8_t> psa_hi;     // only when size > 2^32
   std::vector<uint8_t> bwt;
   std::vector<uint32_t> gt_begin;  // bit u <-> position end-u, u in [0,size)
@@ -195,7 +205,7 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   const double info = sigma >= 2 ? std::log2((double)sigma) / bits : 1.0;
   int need = std::min(used, (int)std::ceil((lg + 8) / info));
   if (need > 32 && (int)std::ceil((lg + 5) / info) <= 32) need = 32;   // the packed 32-bit path below; groups a little larger
-  std::vector<uint32_t> idx((size_t)m);
+  PsaVec idx((size_t)m);
   // work allowed in the group phase before SA-IS is the better tool (4 units per suffix and refinement round, 1 per
   // symbol comparison): natural language needs 3-4 rounds, random text none; periodic text runs out and gives up
   int64_t budget = 24 * m + (1 << 16);
@@ -279,7 +289,7 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
       for (int64_t i = 0; i < m; ++i) idx[(size_t)i] = (uint32_t)kv[(size_t)i];
     } else {
       std::vector<uint64_t> key((size_t)m), key2((size_t)m);
-      std::vector<uint32_t> idx2((size_t)m);
+      PsaVec idx2((size_t)m);
       {
         uint64_t k = 0;
         for (int64_t i = std::min<int64_t>(n, end + per_key) - 1; i >= beg; --i) {
@@ -303,7 +313,7 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
         key.swap(key2); idx.swap(idx2);
       }
       std::vector<uint64_t>().swap(key2);
-      std::vector<uint32_t>().swap(idx2);
+      PsaVec().swap(idx2);
       const int gs = 64 - need;
       std::vector<std::pair<uint64_t, uint32_t>> grp;
       for (int64_t g0 = 0; g0 < m;) {
