@@ -16,6 +16,10 @@
 //                                 cores, and that is the default): sort the half-blocks on the device with the
 //                                 bench's prefix-key sorter (psascan_amd_extras.h; texts whose repeats stay below a
 //                                 few hundred symbols -- anything else falls back to the host sorter)
+//                --checkpoint DIR after every block the run's state goes to DIR (partial SAs as part files, merge
+//                                 bitvectors, gt bits, a manifest renamed into place last); the same command started
+//                                 again resumes behind the last finished block.  The reference has no such thing
+//                                 (SURVEY 8f row 4): a 1 TiB run that dies in block 40 starts over.
 //                --text-on-host [--tail-chunk N]
 //                                 the text stays in host memory (automatic beyond 55 % of the device memory): every
 //                                 pass uploads its tail in chunks of N symbols (default 1 Gi) and streams them one
@@ -94,6 +98,9 @@ static void usage(int status) {
          "      --no-device-merge   sort every half-block in one piece on the host (extension)\n"
          "      --device-sort       suffix-sort the half-blocks on the device (extension; the default keeps\n"
          "                          the sort on the host cores like the reference)\n"
+         "      --checkpoint=DIR    keep the state of the run in DIR after every block (partial SAs, merge\n"
+         "                          bitvectors, gt bits); a run started again with the same arguments resumes\n"
+         "                          behind the last finished block (the reference starts over)\n"
          "      --text-on-host      keep the text in host memory and upload the tail of every pass in chunks\n"
          "                          (automatic for texts beyond 55%% of the device memory); --tail-chunk=N\n",
          program_name);
@@ -145,6 +152,7 @@ struct DoneHalfBlock {
   Dev mbv;
   std::string part_file;          // --spill-psa: [size x u32 low words][size x u8 high bytes, if any]
   bool part_has_hi = false;
+  bool keep_part = false;         // checkpointed run: the file outlives this process until the run completes
   void *map = nullptr;
   size_t map_bytes = 0;
   DoneHalfBlock() {}
@@ -153,12 +161,14 @@ struct DoneHalfBlock {
   DoneHalfBlock(DoneHalfBlock &&o) noexcept { take(o); }
   DoneHalfBlock &operator=(DoneHalfBlock &&o) noexcept { if (this != &o) { drop(); take(o); } return *this; }
   ~DoneHalfBlock() { drop(); }
-  void drop() { if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty()) remove(part_file.c_str()); part_file.clear(); }
+  void drop() { if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
   void take(DoneHalfBlock &o) {
     beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv);
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
+    keep_part = o.keep_part;
   }
   void spill(const std::string &prefix) {
+    if (!part_file.empty()) return;     // already on disk (checkpoint)
     part_file = prefix + ".psa." + std::to_string(beg);
     FILE *f = fopen(part_file.c_str(), "wb");
     bool ok = f && fwrite(psa_lo.data(), 4, (size_t)size, f) == (size_t)size;
@@ -220,6 +230,8 @@ struct Options {
   int64_t tail_chunk = (int64_t)1 << 30;
   bool discard = false, spill_psa = false, hierarchical = true, device_sort = false, text_on_host = false;
   std::string gap_prefix;
+  std::string checkpoint_dir;     // --checkpoint DIR: state on disk after every block; an interrupted run resumes from it
+  int64_t stop_after = 0;         // test hook: stop (exit status 3) after this many blocks of this invocation
 };
 
 static void run(const std::string &text_fn, const std::string &out_fn, uint64_t ram_use, long max_threads, const Options &opt_in) {
@@ -277,6 +289,110 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
 
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
+
+  // ---- --checkpoint DIR.  After every block: the new half-blocks' partial SAs as part files, their merge bitvectors,
+  // the gt bits the next block starts from, then a manifest renamed into place -- whatever a crash leaves behind, the
+  // manifest names only files that were complete before it was written.  Started again with the same text size, block
+  // size and budget, the run loads that state and goes on with the next block.
+  const bool ckpt = !opt.checkpoint_dir.empty();
+  const std::string ck_prefix = opt.checkpoint_dir + "/ckpt";
+  int64_t first_bid = n_blocks - 1;
+  auto write_file = [&](const std::string &fn, const void *data, size_t bytes) {
+    FILE *f = fopen(fn.c_str(), "wb");
+    bool ok = f && fwrite(data, 1, bytes, f) == bytes;
+    if (f) ok = fclose(f) == 0 && ok;
+    if (!ok) throw std::runtime_error("cannot write the checkpoint file " + fn);
+  };
+  auto read_file = [&](const std::string &fn, void *data, size_t bytes) {
+    FILE *f = fopen(fn.c_str(), "rb");
+    bool ok = f && fread(data, 1, bytes, f) == bytes;
+    if (f) fclose(f);
+    if (!ok) throw std::runtime_error("cannot read the checkpoint file " + fn);
+  };
+  size_t ck_saved = 0;                                       // half-blocks already on disk
+  auto checkpoint_block = [&](int64_t bid) {                 // after block bid: hbs, gt_cur are its results
+    if (!ckpt) return;
+    double t1 = wclock();
+    std::vector<uint8_t> hostbuf;
+    for (; ck_saved < hbs.size(); ++ck_saved) {
+      DoneHalfBlock &h = hbs[ck_saved];
+      h.keep_part = true;
+      h.spill(ck_prefix);
+      if (h.mbv.p) {
+        hostbuf.resize((size_t)h.mbv.bytes);
+        CK(psg_d2h(hostbuf.data(), h.mbv.p, h.mbv.bytes));
+        write_file(ck_prefix + ".mbv." + std::to_string(h.beg), hostbuf.data(), hostbuf.size());
+      }
+    }
+    hostbuf.resize((size_t)(4 * gt_words));
+    CK(psg_d2h(hostbuf.data(), gt_cur.p, 4 * gt_words));
+    write_file(ck_prefix + ".gt." + std::to_string(bid), hostbuf.data(), hostbuf.size());
+    const std::string mf = ck_prefix + ".manifest", tmp = mf + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "w");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    fprintf(f, "psascan-mi355x-checkpoint 1\nn %ld block %ld ram %ld\nnext_block %ld\nhalfblocks %zu\n", (long)n, (long)max_block_size, (long)ram_use, (long)(bid - 1), hbs.size());
+    for (const DoneHalfBlock &h : hbs) fprintf(f, "%ld %ld %d %ld\n", (long)h.beg, (long)h.size, (int)h.part_has_hi, (long)(h.mbv.p ? h.mbv.bytes : 0));
+    bool ok = fflush(f) == 0 && fsync(fileno(f)) == 0;
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp.c_str(), mf.c_str()) != 0) throw std::runtime_error("cannot write " + mf);
+    remove((ck_prefix + ".gt." + std::to_string(bid + 1)).c_str());
+    if (g_verbose) fprintf(stderr, "    checkpoint: %.2fs\n", wclock() - t1);
+  };
+  auto checkpoint_clear = [&]() {                            // the run is complete: nothing to resume
+    if (!ckpt) return;
+    remove((ck_prefix + ".manifest").c_str());
+    remove((ck_prefix + ".gt.0").c_str());
+    for (DoneHalfBlock &h : hbs) {
+      remove((ck_prefix + ".mbv." + std::to_string(h.beg)).c_str());
+      h.keep_part = false;                                   // its destructor removes the part file
+    }
+  };
+  if (ckpt) {
+    mkdir(opt.checkpoint_dir.c_str(), 0777);
+    FILE *f = fopen((ck_prefix + ".manifest").c_str(), "r");
+    if (f) {
+      long mn = -1, mb = -1, mr = -1, next = -2; size_t cnt = 0; int ver = 0;
+      bool ok = fscanf(f, "psascan-mi355x-checkpoint %d n %ld block %ld ram %ld next_block %ld halfblocks %zu", &ver, &mn, &mb, &mr, &next, &cnt) == 6 && ver == 1;
+      if (ok && (mn != (long)n || mb != (long)max_block_size || mr != (long)ram_use)) {
+        fclose(f);
+        throw std::runtime_error("the checkpoint in " + opt.checkpoint_dir + " belongs to another run (text length, block size or memory budget differ)");
+      }
+      for (size_t k = 0; ok && k < cnt; ++k) {
+        long hb = 0, hs = 0, mv = 0; int hh = 0;
+        ok = fscanf(f, "%ld %ld %d %ld", &hb, &hs, &hh, &mv) == 4;
+        if (!ok) break;
+        DoneHalfBlock h;
+        h.beg = hb; h.size = hs; h.part_has_hi = hh != 0; h.keep_part = true;
+        h.part_file = ck_prefix + ".psa." + std::to_string(hb);
+        if (mv > 0) {
+          std::vector<uint8_t> buf((size_t)mv);
+          read_file(ck_prefix + ".mbv." + std::to_string(hb), buf.data(), buf.size());
+          h.mbv.alloc(mv);
+          CK(psg_h2d(h.mbv.p, buf.data(), mv));
+        }
+        struct stat sb;
+        if (stat(h.part_file.c_str(), &sb) != 0 || sb.st_size != (off_t)((size_t)hs * (hh ? 5 : 4))) throw std::runtime_error("checkpoint part file missing or short: " + h.part_file);
+        hbs.push_back(std::move(h));
+      }
+      fclose(f);
+      if (!ok) throw std::runtime_error("unreadable checkpoint manifest in " + opt.checkpoint_dir);
+      std::vector<uint8_t> buf((size_t)(4 * gt_words));
+      read_file(ck_prefix + ".gt." + std::to_string(next + 1), buf.data(), buf.size());
+      CK(psg_h2d(gt_cur.p, buf.data(), 4 * gt_words));
+      first_bid = next;
+      ck_saved = hbs.size();
+      fprintf(stderr, "Resuming from the checkpoint in %s: %ld of %ld blocks done\n\n", opt.checkpoint_dir.c_str(), (long)(n_blocks - 1 - first_bid), (long)n_blocks);
+    }
+  }
+  int64_t blocks_this_run = 0;
+  auto end_block = [&](int64_t bid) {
+    checkpoint_block(bid);
+    if (opt.stop_after > 0 && ++blocks_this_run >= opt.stop_after && bid > 0) {
+      fprintf(stderr, "Stopping after %ld blocks (--stop-after)\n", (long)blocks_this_run);
+      fflush(stderr);
+      _exit(3);
+    }
+  };
 
   // One streaming pass.  The chain start ranks normally come out of the warm-up on the device; on text with long
   // repeats some stay open: the pass then reports PSG_EUNRESOLVED, the partial SAs of the block's halves are
@@ -352,7 +468,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t ls = last ? std::min<int64_t>(bs, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, bs / 2);
     if (id & 1) { hb_beg = b + ls; hb_end = e; } else { hb_beg = b; hb_end = b + ls; }
   };
-  for (int64_t bid = n_blocks - 1; bid >= 0; --bid)
+  for (int64_t bid = first_bid; bid >= 0; --bid)
     for (int side = 1; side >= 0; --side) {                  // right half first
       int64_t hb, he;
       half_range(2 * bid + side, hb, he);
@@ -586,7 +702,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     return d;
   };
 
-  for (int64_t bid = n_blocks - 1; bid >= 0; --bid) {   // partial_sufsort.hpp:568
+  for (int64_t bid = first_bid; bid >= 0; --bid) {      // partial_sufsort.hpp:568
     const int64_t b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
     const bool last_block = e == n;
     if (!last_block && bs <= 1) throw std::runtime_error("any block other than the last has to be of length at least two.");
@@ -615,6 +731,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, L.gt.as<uint32_t>(), 0, ls));
       hbs.push_back(std::move(hbL));
       std::swap(gt_cur, gt_new);
+      end_block(bid);
       continue;
     }
     Dev &d_lbwt = L.bwt, &d_rbwt = R.bwt, &d_rgt = R.gt, &d_lgt = L.gt;
@@ -649,6 +766,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
       hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
       std::swap(gt_cur, gt_new);
+      end_block(bid);
       continue;
     }
     // ---- BWT merge (:468-471)
@@ -683,6 +801,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
+    end_block(bid);
   }
   if (inner_passes) {
     fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
@@ -724,6 +843,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples));
     if (!sum_ok || chk.bad_pairs) throw std::runtime_error("output check failed");
   }
+  checkpoint_clear();
   {
     int64_t in_use = 0, peak = 0, reserved = 0;
     psg_mem_stats(&in_use, &peak, &reserved);
@@ -742,7 +862,8 @@ int main(int argc, char **argv) {
                                          {"spill-psa", no_argument, NULL, 1004}, {"leaf-size", required_argument, NULL, 1005},
                                          {"fanout", required_argument, NULL, 1006}, {"no-device-merge", no_argument, NULL, 1007},
                                          {"device-sort", no_argument, NULL, 1008}, {"text-on-host", no_argument, NULL, 1009},
-                                         {"tail-chunk", required_argument, NULL, 1010}, {NULL, 0, NULL, 0}};
+                                         {"tail-chunk", required_argument, NULL, 1010}, {"checkpoint", required_argument, NULL, 1011},
+                                         {"stop-after", required_argument, NULL, 1012}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
   Options opt;
@@ -767,6 +888,8 @@ int main(int argc, char **argv) {
       case 1007: opt.hierarchical = false; break;
       case 1008: opt.device_sort = true; break;
       case 1009: opt.text_on_host = true; break;
+      case 1011: opt.checkpoint_dir = optarg; break;
+      case 1012: opt.stop_after = atoll(optarg); break;
       case 1010: { uint64_t v; if (!parse_number(optarg, &v) || v < 64) { fprintf(stderr, "Error: bad --tail-chunk\n\n"); usage(EXIT_FAILURE); } opt.tail_chunk = (int64_t)v; break; }
       default: usage(EXIT_FAILURE); break;
     }

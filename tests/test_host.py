@@ -432,3 +432,37 @@ def test_cli_edge_inputs(tmp_path):
         assert r.returncode == 0, r.stderr[-500:]
         got = orc.sa5_to_sa(np.frombuffer((tmp_path / "tiny.bin.sa5").read_bytes(), np.uint8))
         assert np.array_equal(got, orc.suffix_array(np.frombuffer(data, np.uint8)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rand", "per3"])
+def test_cli_checkpoint_resume(tmp_path, kind):
+    """--checkpoint DIR (the reference has no restart): the run is stopped after 2 and then after 3 more
+    of its 7 blocks (--stop-after, exit status 3, as a crash would leave it), started again twice, and the .sa5 is the
+    same bytes as an uninterrupted run's.  A checkpoint of another run is refused; a completed run leaves nothing behind."""
+    rng = np.random.default_rng(9)
+    n = 130_001
+    t = rng.integers(0, 5, n, dtype=np.uint8) if kind == "rand" else np.frombuffer((b"abc" * (n // 3 + 1))[:n], np.uint8).copy()
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    base = [CLI, "-m", "1G", "--block-size", "20000", "-v"]
+    ref = tmp_path / "ref.sa5"
+    r = subprocess.run(base + ["-o", str(ref), str(f)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck = tmp_path / "ck"
+    out = tmp_path / "x.sa5"
+    cmd = base + ["--checkpoint", str(ck), "-o", str(out), str(f)]
+    r = subprocess.run(cmd + ["--stop-after", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 3 and "Process block 2/7" in r.stderr and "Process block 3/7" not in r.stderr, r.stderr[-2000:]
+    assert (ck / "ckpt.manifest").exists()
+    # another run's checkpoint is refused
+    r = subprocess.run(base + ["--block-size", "30000", "--checkpoint", str(ck), "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 1 and "belongs to another run" in r.stderr
+    r = subprocess.run(cmd + ["--stop-after", "3"], input="y\n", capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 3 and "2 of 7 blocks done" in r.stderr and "Process block 3/7" in r.stderr and "Process block 2/7" not in r.stderr, r.stderr[-2000:]
+    r = subprocess.run(cmd, input="y\n", capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "5 of 7 blocks done" in r.stderr and "Process block 6/7" in r.stderr and "Process block 5/7" not in r.stderr, r.stderr[-2000:]
+    assert out.read_bytes() == ref.read_bytes()
+    assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
+    assert sorted(os.listdir(ck)) == []
