@@ -129,6 +129,9 @@ static bool file_exists(const std::string &f) { FILE *fp = fopen(f.c_str(), "r")
 #define CK(call)                                                                                      \
   do { int rc_ = (call); if (rc_ != 0) throw std::runtime_error(std::string(#call) + ": " + psg_last_error()); } while (0)
 
+static void pending_downloads_wait();
+static double g_alloc_seconds = 0, g_free_seconds = 0;   // time inside the device allocator (verbose summary)
+static double wclock_raw() { timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + tv.tv_usec * 1e-6; }
 struct Dev {  // owning device buffer
   void *p = nullptr;
   int64_t bytes = 0;
@@ -139,17 +142,55 @@ struct Dev {  // owning device buffer
   Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
   Dev &operator=(Dev &&o) noexcept { release(); p = o.p; bytes = o.bytes; o.p = nullptr; return *this; }
   ~Dev() { release(); }
-  void alloc(int64_t b, bool zero = false) { release(); bytes = b < 16 ? 16 : b; CK(psg_malloc(&p, bytes)); if (zero) CK(psg_memset(p, 0, bytes)); }
-  void release() { if (p) { psg_free(p); p = nullptr; } }
+  void alloc(int64_t b, bool zero = false) {
+    release(); bytes = b < 16 ? 16 : b;
+    const double t0 = wclock_raw();
+    if (psg_malloc(&p, bytes) == PSG_ENOMEM) { pending_downloads_wait(); CK(psg_malloc(&p, bytes)); }   // partial SAs on their way to the host hold device memory
+    g_alloc_seconds += wclock_raw() - t0;
+    if (zero) CK(psg_memset(p, 0, bytes));
+  }
+  void release() { if (p) { const double t0 = wclock_raw(); psg_free(p); p = nullptr; g_free_seconds += wclock_raw() - t0; } }
   template <class T> T *as() const { return (T *)p; }
 };
+
+// the partial SA of a half-block that was built on the device, on its way to host memory in the background
+// (psg_d2h_begin: worker thread + own stream; the device copy is freed by the worker the moment it is drained)
+struct PendingPsa {
+  psg_copy_t *c_lo = nullptr, *c_hi = nullptr;
+  static std::mutex &mu() { static std::mutex m; return m; }
+  static std::vector<PendingPsa *> &all() { static std::vector<PendingPsa *> v; return v; }
+  PendingPsa() { std::lock_guard<std::mutex> lk(mu()); all().push_back(this); }
+  void wait() {
+    const int r1 = psg_copy_wait(c_lo); c_lo = nullptr;
+    const int r2 = psg_copy_wait(c_hi); c_hi = nullptr;
+    if (r1 || r2) throw std::runtime_error(std::string("download of a partial suffix array: ") + psg_last_error());
+  }
+  ~PendingPsa() {
+    (void)psg_copy_wait(c_lo); (void)psg_copy_wait(c_hi);
+    std::lock_guard<std::mutex> lk(mu());
+    auto &v = all();
+    v.erase(std::remove(v.begin(), v.end(), this), v.end());
+  }
+  // device memory is short: wait until every download in flight has handed its source back
+  static void wait_all() { std::lock_guard<std::mutex> lk(mu()); for (PendingPsa *p : all()) p->wait(); }
+};
+
+static void pending_downloads_wait() { PendingPsa::wait_all(); }
+// a library call that allocates its own temporaries: once more after the downloads in flight have released theirs
+template <class F> static int with_memory_retry(F &&f) {
+  int rc = f();
+  if (rc == PSG_ENOMEM) { pending_downloads_wait(); (void)psg_trim(); rc = f(); }
+  return rc;
+}
 
 // a finished half-block: the partial SA stays in host memory (or in a part file, --spill-psa), the merge bitvector in HBM
 struct DoneHalfBlock {
   int64_t beg = 0, size = 0;
   psa_host::PsaVec psa_lo;
-  std::vector<uint8_t> psa_hi;
+  psa_host::PsaHiVec psa_hi;
   Dev mbv;
+  std::unique_ptr<PendingPsa> pend;   // psa_lo / psa_hi are still being written (settle() before the host reads them)
+  void settle() { if (pend) { pend->wait(); pend.reset(); } }
   std::string part_file;          // --spill-psa: [size x u32 low words][size x u8 high bytes, if any]
   bool part_has_hi = false;
   bool keep_part = false;         // checkpointed run: the file outlives this process until the run completes
@@ -161,14 +202,15 @@ struct DoneHalfBlock {
   DoneHalfBlock(DoneHalfBlock &&o) noexcept { take(o); }
   DoneHalfBlock &operator=(DoneHalfBlock &&o) noexcept { if (this != &o) { drop(); take(o); } return *this; }
   ~DoneHalfBlock() { drop(); }
-  void drop() { if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
+  void drop() { pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
   void take(DoneHalfBlock &o) {
-    beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv);
+    beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend);
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
     keep_part = o.keep_part;
   }
   void spill(const std::string &prefix) {
     if (!part_file.empty()) return;     // already on disk (checkpoint)
+    settle();
     part_file = prefix + ".psa." + std::to_string(beg);
     FILE *f = fopen(part_file.c_str(), "wb");
     bool ok = f && fwrite(psa_lo.data(), 4, (size_t)size, f) == (size_t)size;
@@ -177,7 +219,7 @@ struct DoneHalfBlock {
     if (f) ok = fclose(f) == 0 && ok;
     if (!ok) throw std::runtime_error("cannot write the part file " + part_file);
     psa_host::PsaVec().swap(psa_lo);
-    std::vector<uint8_t>().swap(psa_hi);
+    psa_host::PsaHiVec().swap(psa_hi);
   }
   void map_back() {
     if (part_file.empty()) return;
@@ -398,7 +440,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // repeats some stay open: the pass then reports PSG_EUNRESOLVED, the partial SAs of the block's halves are
   // uploaded (they live in host memory) and the pass is repeated with a search context -- the open starts are
   // found by string search over them (em_compute_initial_ranks.hpp:222-319), still in one kernel launch.
-  struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const std::vector<uint8_t> *hi; };
+  struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const psa_host::PsaHiVec *hi; DoneHalfBlock *owner; };
   auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
                          uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
                          psg_stream_stats *st) {
@@ -428,7 +470,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     a.rank = rank; a.block_i0 = i0; a.block_last_symbol = last_sym; a.d_tail = d_text.as<uint8_t>() + tail_beg; a.tail_len = T; a.right_context = 0;
     a.d_gt_in = d_gt_in; a.rank_at_context_end = rank_at_end; a.d_gap = d_gap; a.d_gt_out = d_gt_out; a.max_chains = max_chains;
     a.flags = PSG_GAP_UNINITIALIZED | PSG_FAIL_IF_UNRESOLVED; a.search = nullptr; a.tail_begin_abs = tail_beg;
-    int rc = psg_stream_gap_args(&a, nullptr, st);
+    int rc = with_memory_retry([&] { return psg_stream_gap_args(&a, nullptr, st); });
     if (rc == PSG_EUNRESOLVED) {
       double t1 = wclock();
       psg_search_ctx sc{};
@@ -436,6 +478,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       sc.nparts = (int)parts.size();
       std::vector<Dev> up;
       for (size_t k = 0; k < parts.size(); ++k) {
+        parts[k].owner->settle();
         up.push_back(upload(parts[k].lo->data(), 4 * parts[k].size));
         sc.part[k].beg = parts[k].beg; sc.part[k].size = parts[k].size; sc.part[k].d_psa_lo = up.back().as<uint32_t>(); sc.part[k].d_psa_hi = nullptr;
         if (!parts[k].hi->empty()) { up.push_back(upload(parts[k].hi->data(), parts[k].size)); sc.part[k].d_psa_hi = up.back().as<uint8_t>(); }
@@ -473,8 +516,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       int64_t hb, he;
       half_range(2 * bid + side, hb, he);
       if (he <= hb) continue;
-      // (the merged partial SA holds 32-bit positions: a half-block of 2^32 symbols or more is sorted in one piece)
-      const int64_t nleaves = lookahead && opt.hierarchical && he - hb < ((int64_t)1 << 32) ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
+      const int64_t nleaves = lookahead && opt.hierarchical ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
       std::vector<int64_t> ids;
       for (int64_t k = nleaves - 1; k >= 0; --k) {           // rightmost leaf first
         const int64_t lb = hb + (he - hb) * k / nleaves, le = hb + (he - hb) * (k + 1) / nleaves;
@@ -557,7 +599,9 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // ---- in-HBM merge of sorted sub-ranges into the partial SA of their union (inmem_psascan.hpp:233-304): the block
   // schedule in small -- sub-range i streams the sub-ranges to its right through its rank structure, the gap array
   // becomes its merge bitvector, one merge yields the union's partial SA; BWT, i0 and gt_begin follow from it.
-  struct DevNode { int64_t beg = 0, size = 0, i0 = 0; Dev psa, bwt, gt; };
+  // (a node of 2^32 positions or more -- the 8 GiB half-blocks of 16 GiB blocks -- carries bits 32..39 in psa_hi)
+  struct DevNode { int64_t beg = 0, size = 0, i0 = 0; Dev psa, psa_hi, bwt, gt; };
+  const int64_t wide_from = getenv("PSASCAN_TEST_WIDE_NODES") ? 1 : ((int64_t)1 << 32);   // test hook: every merged node gets a high plane
   int64_t inner_passes = 0, inner_suffixes = 0;
   double tm_upload = 0, tm_search = 0, tm_rank = 0, tm_stream = 0, tm_bv = 0, tm_merge = 0, tm_finish = 0;   // where the merging spends its time
   psg_search_ctx sc_text{};                                  // comparisons by reading on in the text (cmp_end = n)
@@ -583,13 +627,13 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       DevNode &c = ch[(size_t)i];
       const int64_t x1 = c.beg + c.size, T = e - x1;
       psg_search_ctx sc = sc_text;
-      sc.nparts = 1; sc.part[0].beg = c.beg; sc.part[0].size = c.size; sc.part[0].d_psa_lo = c.psa.as<uint32_t>(); sc.part[0].d_psa_hi = nullptr;
+      sc.nparts = 1; sc.part[0].beg = c.beg; sc.part[0].size = c.size; sc.part[0].d_psa_lo = c.psa.as<uint32_t>(); sc.part[0].d_psa_hi = c.psa_hi.as<uint8_t>();
       int64_t r_end = 0;
       double tq = wclock();
       if (e < n) CK(psg_initial_ranks(&sc, &e, 1, &r_end));
       tm_search += wclock() - tq; tq = wclock();
       psg_rank_t *rk = nullptr;
-      CK(psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk));
+      CK(with_memory_retry([&] { return psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk); }));
       tm_rank += wclock() - tq; tq = wclock();
       Dev gap(4 * psg_gap_words(c.size), false);
       CK(psg_memset(gt_n.p, 0, gt_n.bytes));
@@ -598,7 +642,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       a.d_gt_in = gt_c.as<uint32_t>(); a.rank_at_context_end = r_end; a.d_gap = gap.as<uint32_t>(); a.d_gt_out = gt_n.as<uint32_t>(); a.max_chains = max_chains;
       a.flags = PSG_GAP_UNINITIALIZED | PSG_SEARCH_ALL_STARTS; a.search = &sc; a.tail_begin_abs = x1;   // leaves sorted with a bounded look-ahead: no long repeats here
       psg_stream_stats st;
-      if (psg_stream_gap_args(&a, nullptr, &st)) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
+      if (with_memory_retry([&] { return psg_stream_gap_args(&a, nullptr, &st); })) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
       psg_rank_free(rk);
       tm_stream += wclock() - tq; tq = wclock();
       ++inner_passes; inner_suffixes += T;
@@ -613,20 +657,22 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     double tq = wclock();
     std::vector<psg_hb_desc> desc((size_t)f);
     for (int i = 0; i < f; ++i)
-      desc[(size_t)i] = psg_hb_desc{ch[(size_t)i].beg - b, ch[(size_t)i].size, ch[(size_t)i].psa.as<uint32_t>(), nullptr, i + 1 < f ? mbv[(size_t)i].as<uint32_t>() : nullptr};
+      desc[(size_t)i] = psg_hb_desc{ch[(size_t)i].beg - b, ch[(size_t)i].size, ch[(size_t)i].psa.as<uint32_t>(), ch[(size_t)i].psa_hi.as<uint8_t>(), i + 1 < f ? mbv[(size_t)i].as<uint32_t>() : nullptr};
     psg_merge_plan_t *plan = nullptr;
     CK(psg_merge_plan_create(desc.data(), f, &plan));
     DevNode out;
     out.beg = b; out.size = R;
     out.psa.alloc(4 * R + 16);
-    int mrc = psg_merge_run_u32(plan, 0, R, out.psa.as<uint32_t>());
+    const bool wide = R >= wide_from;
+    if (wide) out.psa_hi.alloc(R + 16);
+    int mrc = wide ? psg_merge_run_planes(plan, 0, R, out.psa.as<uint32_t>(), out.psa_hi.as<uint8_t>()) : psg_merge_run_u32(plan, 0, R, out.psa.as<uint32_t>());
     psg_merge_plan_free(plan);
-    if (mrc) throw std::runtime_error(std::string("psg_merge_run_u32: ") + psg_last_error());
+    if (mrc) throw std::runtime_error(std::string("merge of sub-ranges: ") + psg_last_error());
     ch.clear();                                               // the children's arrays are dead
     tm_merge += wclock() - tq; tq = wclock();
     out.bwt.alloc(R + 16);
     out.gt.alloc(4 * gtw, true);
-    CK(psg_halfblock_from_psa(&sc_text, b, R, out.psa.as<uint32_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()));
+    CK(psg_halfblock_from_psa40(&sc_text, b, R, out.psa.as<uint32_t>(), out.psa_hi.as<uint8_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()));
     tm_finish += wclock() - tq;
     return out;
   };
@@ -641,25 +687,67 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   };
 
   // one half-block, ready for the block schedule: BWT and gt_begin in HBM, the partial SA in host memory
-  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; psa_host::PsaVec psa_lo; std::vector<uint8_t> psa_hi; std::vector<uint32_t> gt_host; };
+  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; psa_host::PsaVec psa_lo; psa_host::PsaHiVec psa_hi; std::vector<uint32_t> gt_host; std::unique_ptr<PendingPsa> pend;
+                int64_t query_rank = 0; bool have_query_rank = false; };
   auto gt_host_of = [&](Half &h) -> const std::vector<uint32_t> & {   // gt_begin on the host (sequential sorter of the half to the left)
     if (h.gt_host.empty()) { h.gt_host.resize((size_t)((h.size + 31) / 32 + 1)); CK(psg_d2h(h.gt_host.data(), h.gt.p, 4 * (int64_t)h.gt_host.size())); }
     return h.gt_host;
   };
-  auto make_half = [&](int64_t id, int64_t hb, int64_t he, const psa_host::GtTail &gt_tail, const char *what) {
+  // query_pos >= 0: also the rank of text[query_pos..) among the half-block's suffixes, if the half-block is built on the device
+  auto make_half = [&](int64_t id, int64_t hb, int64_t he, const psa_host::GtTail &gt_tail, const char *what, int64_t query_pos) {
     Half H;
     H.beg = hb; H.size = he - hb;
     const double t0 = wclock();
-    if (opt.device_sort && H.size < ((int64_t)1 << 32)) {
+    auto take_root = [&](DevNode &root) {                      // the merged node becomes the half-block: partial SA to the host
+      H.i0 = root.i0;
+      H.bwt = std::move(root.bwt); H.gt = std::move(root.gt);
+      if (query_pos >= 0) {                                   // while the partial SA is on the device: K8 (em_compute_initial_ranks.hpp:222-319)
+        psg_search_ctx sc = sc_text;
+        sc.nparts = 1; sc.part[0].beg = hb; sc.part[0].size = H.size; sc.part[0].d_psa_lo = root.psa.as<uint32_t>(); sc.part[0].d_psa_hi = root.psa_hi.as<uint8_t>();
+        CK(psg_initial_ranks(&sc, &query_pos, 1, &H.query_rank));
+        H.have_query_rank = true;
+      }
+      H.psa_lo.resize((size_t)H.size);                        // (default-initialised: the download is the first touch)
+      std::unique_ptr<PendingPsa> P(new PendingPsa());
+      CK(psg_d2h_begin(H.psa_lo.data(), root.psa.p, 4 * H.size, 1, &P->c_lo));
+      root.psa.p = nullptr;                                   // the worker frees it when it is drained
+      if (root.psa_hi.p) {
+        H.psa_hi.resize((size_t)H.size);
+        CK(psg_d2h_begin(H.psa_hi.data(), root.psa_hi.p, H.size, 1, &P->c_hi));
+        root.psa_hi.p = nullptr;
+      }
+      H.pend = std::move(P);                                  // in the background: the schedule goes on with the next sort / pass
+    };
+    if (opt.device_sort) {
       // same input restriction as the host sorter and the reference (initial_partial_sufsort.hpp:141-146)
       if (memchr(text.data() + hb, 255, (size_t)H.size)) throw std::runtime_error("the input contains byte 255");
-      Dev psa(4 * H.size + 16), bwt(H.size + 16), gt(4 * ((H.size + 31) / 32 + 2), true);
-      int64_t i0 = -1, ties = 0;
-      if (psgx_sort_halfblock(d_text.as<uint8_t>(), n, hb, he, psa.as<uint32_t>(), bwt.as<uint8_t>(), &i0, gt.as<uint32_t>(), &ties) == 0) {
-        H.i0 = i0;
-        H.psa_lo.resize((size_t)H.size);
-        CK(psg_d2h(H.psa_lo.data(), psa.p, 4 * H.size));
-        H.bwt = std::move(bwt); H.gt = std::move(gt);
+      // the device sorter holds 32-bit positions: a half-block of 2^32 symbols or more (or --leaf-size with --device-sort:
+      // pieces of that size) is sorted in pieces that are merged like host-sorted leaves
+      const int64_t piece_max = opt.leaf_size > 0 ? opt.leaf_size : ((int64_t)1 << 31);
+      const int64_t np = H.size < ((int64_t)1 << 32) && opt.leaf_size <= 0 ? 1 : (H.size + piece_max - 1) / piece_max;
+      std::vector<DevNode> pieces;
+      bool ok = true;
+      for (int64_t k = 0; k < np && ok; ++k) {
+        DevNode d;
+        d.beg = hb + H.size * k / np; d.size = hb + H.size * (k + 1) / np - d.beg;
+        d.psa.alloc(4 * d.size + 16); d.bwt.alloc(d.size + 16); d.gt.alloc(4 * ((d.size + 31) / 32 + 2), true);
+        int64_t ties = 0;
+        const int src = with_memory_retry([&] { return psgx_sort_halfblock(d_text.as<uint8_t>(), n, d.beg, d.beg + d.size, d.psa.as<uint32_t>(), d.bwt.as<uint8_t>(), &d.i0, d.gt.as<uint32_t>(), &ties); });
+        if (src == PSG_ENOMEM) throw std::runtime_error(std::string("device sufsort: ") + psg_last_error());   // not a reason to sort gigabytes on one host thread
+        ok = src == 0;
+        if (ok) pieces.push_back(std::move(d));
+      }
+      if (ok) {
+        if (np == 1) take_root(pieces[0]);
+        else {
+          const double t1 = wclock();
+          const int64_t p0 = inner_passes;
+          DevNode root = merge_nodes(pieces);
+          const double t2 = wclock();
+          take_root(root);
+          if (g_verbose) fprintf(stderr, "      hand-over of the partial SA: %.2fs\n", wclock() - t2);
+          if (g_verbose) fprintf(stderr, "      %ld pieces sorted on the device, merged in %.2fs (%ld passes)\n", (long)np, wclock() - t1, (long)(inner_passes - p0));
+        }
         log_phase((std::string("device sufsort (") + what + " half)").c_str(), t0, H.size);
         return H;
       }
@@ -686,10 +774,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       const size_t nl = leaves.size();
       const int64_t p0 = inner_passes, s0 = inner_suffixes;
       DevNode root = build_tree(leaves, 0, nl);
-      H.i0 = root.i0;
-      H.psa_lo.resize((size_t)H.size);
-      CK(psg_d2h(H.psa_lo.data(), root.psa.p, 4 * H.size));
-      H.bwt = std::move(root.bwt); H.gt = std::move(root.gt);
+      take_root(root);
       fprintf(stderr, "    sufsort (%s half): %zu leaves sorted ahead on the host (waited %.2fs), merged on the device in %.2fs (%ld passes, %.1f Mi suffixes streamed)\n",
               what, nl, t_wait, wclock() - t0 - t_wait, (long)(inner_passes - p0), (inner_suffixes - s0) / 1048576.0);
     }
@@ -699,6 +784,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     DoneHalfBlock d;
     d.beg = h.beg; d.size = h.size;
     d.psa_lo.swap(h.psa_lo); d.psa_hi.swap(h.psa_hi);
+    d.pend = std::move(h.pend);
     return d;
   };
 
@@ -717,13 +803,13 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u);
     };
     Half R, L;
-    if (rs > 0) R = make_half(2 * bid + 1, mid, e, gt_tail_e, "right");
+    if (rs > 0) R = make_half(2 * bid + 1, mid, e, gt_tail_e, "right", -1);
     auto gt_tail_mid = [&](int64_t v) {  // position mid+v in (mid, e]: right half's gt_begin, u = e - j
       if (rs == 0) return gt_tail_e(v);
       int64_t u = e - (mid + v);
       return (bool)((gt_host_of(R)[(size_t)(u >> 5)] >> (u & 31)) & 1u);
     };
-    L = make_half(2 * bid, b, mid, gt_tail_mid, "left");
+    L = make_half(2 * bid, b, mid, gt_tail_mid, "left", rs > 0 ? e : -1);
     double t0 = wclock();
     if (rs == 0) {
       DoneHalfBlock hbL = keep_half(L);
@@ -738,19 +824,23 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     // ---- pass A (partial_sufsort.hpp:403-414)
     t0 = wclock();
     psg_rank_t *rankL = nullptr;
-    CK(psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL));
+    CK(with_memory_retry([&] { return psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL); }));
     log_phase("Construct rank (left half, device)", t0, ls);
     Dev gapA(4 * psg_gap_words(ls), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
-    HalfBlock Lview;                                          // rank of text[e..) among the left half's suffixes: host search over its partial SA
-    Lview.beg = b; Lview.size = ls; Lview.psa_lo.swap(L.psa_lo); Lview.psa_hi.swap(L.psa_hi);
-    int64_t initA = psa_host::rank_by_search(text.data(), n, Lview, e);
-    L.psa_lo.swap(Lview.psa_lo); L.psa_hi.swap(Lview.psa_hi);
+    int64_t initA = 0;                                        // rank of text[e..) among the left half's suffixes
+    if (L.have_query_rank) initA = L.query_rank;              // found on the device before the partial SA left it
+    else {                                                  // host search over the partial SA
+      HalfBlock Lview;
+      Lview.beg = b; Lview.size = ls; Lview.psa_lo.swap(L.psa_lo); Lview.psa_hi.swap(L.psa_hi);
+      initA = psa_host::rank_by_search(text.data(), n, Lview, e);
+      L.psa_lo.swap(Lview.psa_lo); L.psa_hi.swap(Lview.psa_hi);
+    }
     const int64_t L_i0 = L.i0, R_i0 = R.i0;
     DoneHalfBlock hbL = keep_half(L), hbR = keep_half(R);
     psg_stream_stats st;
     t0 = wclock();
     stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
-                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi}}, &st);
+                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}}, &st);
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankL);
@@ -779,14 +869,14 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     // ---- pass B (:500-514)
     t0 = wclock();
     psg_rank_t *rankB = nullptr;
-    CK(psg_rank_build(d_bbwt.as<uint8_t>(), bs, 0, &rankB));
+    CK(with_memory_retry([&] { return psg_rank_build(d_bbwt.as<uint8_t>(), bs, 0, &rankB); }));
     d_bbwt.release();
     log_phase("Construct rank (block, device)", t0, bs);
     const int64_t T = n - e;
     Dev gapB(4 * psg_gap_words(bs), false);
     t0 = wclock();
     stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(), gt_new.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
-                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi}}, &st);
+                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi, &hbR}}, &st);
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     psg_rank_free(rankB);
@@ -805,6 +895,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   }
   if (inner_passes) {
     fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
+    if (g_verbose) fprintf(stderr, "    device allocator: %.2fs in psg_malloc, %.2fs in psg_free (host side)\n", g_alloc_seconds, g_free_seconds);
     if (g_verbose) fprintf(stderr, "    seconds: leaf upload %.2f, start-rank search %.2f, rank build %.2f, stream pass %.2f, gap->bitvector %.2f, merge %.2f, BWT/gt from PSA %.2f\n",
                            tm_upload, tm_search, tm_rank, tm_stream, tm_bv, tm_merge, tm_finish);
   }
@@ -817,6 +908,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   std::sort(hbs.begin(), hbs.end(), [](const DoneHalfBlock &a, const DoneHalfBlock &b) { return a.beg < b.beg; });
   std::vector<psg_hb_host_desc> desc(hbs.size());
   for (size_t h = 0; h < hbs.size(); ++h) {
+    hbs[h].settle();
     hbs[h].map_back();
     desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr, nullptr, nullptr};
   }

@@ -32,11 +32,12 @@ template <class T> struct default_init_alloc : std::allocator<T> {
   }
 };
 typedef std::vector<uint32_t, default_init_alloc<uint32_t>> PsaVec;
+typedef std::vector<uint8_t, default_init_alloc<uint8_t>> PsaHiVec;
 
 struct HalfBlock {
   int64_t beg = 0, size = 0, i0 = 0;
   PsaVec psa_lo;
-  std::vector<uint8_t> psa_hi;     // only when size > 2^32
+  PsaHiVec psa_hi;                 // only when size > 2^32
   std::vector<uint8_t> bwt;
   std::vector<uint32_t> gt_begin;  // bit u <-> position end-u, u in [0,size)
 };

@@ -54,6 +54,14 @@ int psg_sync(void);
 /* page-locked host memory: psg_h2d / psg_d2h / psg_merge_stream copy from / to it without a staging step */
 int psg_host_alloc(void **h_ptr, int64_t bytes);
 int psg_host_free(void *h_ptr);
+/* download in the background: a worker thread with its own stream and pinned staging drains d_src into (pageable)
+ * host memory while the library's stream goes on; h_dst stays untouched until psg_copy_wait (which returns the
+ * copy's status and frees the handle).  free_src != 0: d_src (from psg_malloc) is handed to the library and
+ * freed the moment it is drained; otherwise it stays the caller's and must live until psg_copy_wait.  The work
+ * enqueued before the call is complete when it returns.                                                       */
+typedef struct psg_copy psg_copy_t;
+int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_copy_t **out);
+int psg_copy_wait(psg_copy_t *copy);
 /* device memory: bytes handed out by psg_malloc right now / the highest value so far / held from the driver */
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved);
 /* the device's memory as the driver sees it (hipMemGetInfo) */
@@ -246,6 +254,12 @@ int psg_merge_run_u32(const psg_merge_plan_t *plan, int64_t out_begin, int64_t o
  * sc: text + comparison end + gt bits as for psg_initial_ranks (parts unused); d_gt_begin may be NULL.        */
 int psg_halfblock_from_psa(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa, uint8_t *d_bwt,
                            int64_t *i0, uint32_t *d_gt_begin);
+/* the two above for ranges of 2^32 positions or more (the 8 GiB half-blocks of BASELINE configs[3]'s 16 GiB blocks):
+ * values of up to 40 bits in two planes, d_lo[k] = low 32 bits, d_hi[k] = bits 32..39 -- the layout psg_hb_desc
+ * and the search parts take.  d_psa_hi may be NULL when size < 2^32.                                            */
+int psg_merge_run_planes(const psg_merge_plan_t *plan, int64_t out_begin, int64_t out_count, uint32_t *d_lo, uint8_t *d_hi);
+int psg_halfblock_from_psa40(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa_lo, const uint8_t *d_psa_hi,
+                             uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin);
 
 /* ---- merge<T> with the partial suffix arrays in HOST memory.  The reference keeps every partial SA in part files
  *      (io/distributed_file.hpp:58-67) and streams them back during the merge (merge.hpp:72-81, 143; parts

@@ -277,12 +277,41 @@ def merge_run_u32(plan, out_begin, out_count, d_out):
     check(lib().psg_merge_run_u32(plan.h, out_begin, out_count, _ptr(d_out)))
 
 
-def halfblock_from_psa(sc, beg, size, d_psa, want_gt=True):
-    """-> (d_bwt, i0, d_gt_begin): BWT (dummy 0 at i0), i0 and gt_begin of text[beg..beg+size) from its partial SA"""
+class BackgroundDownload:
+    """psg_d2h_begin: a device buffer drains into a host array on a worker thread with its own stream while the
+    library's stream goes on; wait() returns the array.  free_src hands the device buffer to the library."""
+
+    def __init__(self, d_src, dtype, count, free_src=False):
+        self.array = np.empty(count, dtype)
+        h = C.c_void_p()
+        check(lib().psg_d2h_begin(self.array.ctypes.data_as(C.c_void_p), _ptr(d_src), self.array.nbytes, 1 if free_src else 0, C.byref(h)))
+        self.h = h.value
+        self._keep = None if free_src else d_src
+        if free_src and hasattr(d_src, "ptr"):
+            d_src.ptr = None                          # no longer ours
+
+    def wait(self):
+        if self.h:
+            h, self.h = self.h, None
+            check(lib().psg_copy_wait(h))
+        return self.array
+
+
+def merge_run_planes(plan, out_begin, out_count, d_lo, d_hi):
+    """merged order as values of up to 40 bits in two planes (u32 low words, u8 bits 32..39)"""
+    check(lib().psg_merge_run_planes(plan.h, out_begin, out_count, _ptr(d_lo), _ptr(d_hi)))
+
+
+def halfblock_from_psa(sc, beg, size, d_psa, want_gt=True, d_psa_hi=None):
+    """-> (d_bwt, i0, d_gt_begin): BWT (dummy 0 at i0), i0 and gt_begin of text[beg..beg+size) from its partial SA
+    (d_psa_hi: the plane of bits 32..39, for ranges of 2^32 positions or more)"""
     d_bwt = DeviceBuffer(size + 16)
     d_gt = zeros(4 * ((size + 31) // 32 + 2)) if want_gt else None
     i0 = C.c_int64(-1)
-    check(lib().psg_halfblock_from_psa(C.byref(sc), beg, size, _ptr(d_psa), d_bwt.ptr, C.byref(i0), _ptr(d_gt)))
+    if d_psa_hi is None:
+        check(lib().psg_halfblock_from_psa(C.byref(sc), beg, size, _ptr(d_psa), d_bwt.ptr, C.byref(i0), _ptr(d_gt)))
+    else:
+        check(lib().psg_halfblock_from_psa40(C.byref(sc), beg, size, _ptr(d_psa), _ptr(d_psa_hi), d_bwt.ptr, C.byref(i0), _ptr(d_gt)))
     return d_bwt, i0.value, d_gt
 
 

@@ -563,8 +563,10 @@ __device__ __forceinline__ void merge_level_loads(const MergeLevel &L, i64 q0, i
 // into the other slot buffer and form a contiguous range of the next level.
 // OUT32: the values (below 2^32: positions inside one half-block) leave as plain u32 instead of packed uint40 -- the
 // merge of sub-blocks into a half-block's partial SA (in-memory pSAscan, inmem_psascan.hpp:64-304)
-template <bool HI, bool OUT32 = false>
-__global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out) {
+// OUT = 2: two planes, the low 32 bits and the bits above -- the same merge when the enclosing range has 2^32 positions
+// or more (half-blocks of configs[3]'s 16 GiB blocks)
+template <bool HI, int OUT = 0>
+__global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, u8 *out, u8 *out_hi) {
   __shared__ u32 scratch[8];
   __shared__ __attribute__((aligned(16))) u16 cur[2][MT];
   __shared__ __attribute__((aligned(16))) u32 vlo[MT];
@@ -624,9 +626,13 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
     q0 = ones_q0; cnt = (int)tot1; s ^= 1; identity = false;
   }
   __syncthreads();
-  if (OUT32) {
+  if (OUT != 0) {
     u32 *o32 = (u32 *)out + (x0 - out_begin);
     for (int k = threadIdx.x; k < len; k += PSG_WG) o32[k] = vlo[k];
+    if (OUT == 2) {
+      u8 *o8 = out_hi + (x0 - out_begin);
+      for (int k = threadIdx.x; k < len; k += PSG_WG) o8[k] = vhi[k];
+    }
     return;
   }
   // pack 40-bit little-endian (types/uint40.hpp:42-104): 4 entries -> 5 dwords, staged in LDS (the slot
@@ -790,8 +796,8 @@ static int merge_launch(int H, const MergeLevel *d_levels, const MergeLevel &L0,
     if (any_hi) hipLaunchKernelGGL(merge2_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
     else hipLaunchKernelGGL(merge2_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
   } else {
-    if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out);
-    else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out);
+    if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out, (u8 *)nullptr);
+    else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out, (u8 *)nullptr);
   }
   PSG_HIP(hipGetLastError());
   return 0;
@@ -804,7 +810,25 @@ extern "C" int psg_merge_run_u32(const psg_merge_plan_t *p, int64_t out_begin, i
   for (const MergeLevel &L : p->levels) PSG_REQUIRE(!L.hi && L.beg + L.size <= 0x100000000ll, "psg_merge_run_u32: values must fit 32 bits");
   if (out_count == 0) return 0;
   EventTimer tm; tm.start();
-  hipLaunchKernelGGL((merge_kernel<false, true>), dim3((unsigned)cdiv(out_count, MT)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_out);
+  hipLaunchKernelGGL((merge_kernel<false, 1>), dim3((unsigned)cdiv(out_count, MT)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_out, (u8 *)nullptr);
+  PSG_HIP(hipGetLastError());
+  tm.stop();
+  PSG_HIP(psg::sync_stream());
+  note_kernel_ms(tm.ms());
+  return 0;
+}
+
+// the same with values of up to 40 bits, as two planes (d_lo[k] = low 32 bits, d_hi[k] = bits 32..39): the partial SA
+// of a range of 2^32 positions or more in the layout every consumer of partial SAs takes (psg_hb_desc, search parts)
+extern "C" int psg_merge_run_planes(const psg_merge_plan_t *p, int64_t out_begin, int64_t out_count, uint32_t *d_lo, uint8_t *d_hi) {
+  PSG_REQUIRE(p && d_lo && d_hi && out_begin >= 0 && out_count >= 0 && out_begin + out_count <= p->n, "psg_merge_run_planes: range");
+  if (out_count == 0) return 0;
+  bool any_hi = false;
+  for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
+  EventTimer tm; tm.start();
+  const unsigned grid = (unsigned)cdiv(out_count, MT);
+  if (any_hi) hipLaunchKernelGGL((merge_kernel<true, 2>), dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_lo, d_hi);
+  else hipLaunchKernelGGL((merge_kernel<false, 2>), dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_lo, d_hi);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());

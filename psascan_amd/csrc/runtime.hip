@@ -477,6 +477,67 @@ int psg_host_free(void *h_ptr) {
   PSG_HIP(hipHostFree(h_ptr));
   return 0;
 }
+// ---- download in the background: a worker thread with its own stream and its own pair of pinned staging buffers
+// drains a device buffer into (pageable) host memory while the library's stream goes on with the next kernels.
+// construct_sa uses it for the partial SA of a finished half-block (4-5 bytes per symbol into fresh host memory:
+// page faults bound the rate at ~10 GiB/s, which used to be a third of a --device-sort run).
+struct psg_copy {
+  std::thread th;
+  int rc = 0;
+  std::string err;
+};
+int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_copy_t **out) {
+  PSG_REQUIRE(out && bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "psg_d2h_begin");
+  PSG_HIP(psg::sync_stream());          // the source is complete before the worker reads it
+  int dev = 0;
+  PSG_HIP(hipGetDevice(&dev));
+  psg_copy *c = new psg_copy();
+  c->th = std::thread([=]() {
+    auto fail = [&](const char *what, hipError_t e) { c->rc = PSG_EDEVICE; c->err = std::string("psg_d2h_begin worker: ") + what + ": " + hipGetErrorString(e); };
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) { fail("hipSetDevice", e); return; }
+    struct Release { void *p; ~Release() { if (p) psg::pool_free(p); } } release{free_src ? d_src : nullptr};   // the source goes back to the allocator the moment it is drained
+    if (bytes == 0) return;
+    hipStream_t st = nullptr;
+    char *pin = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const size_t total = (size_t)bytes, piece = std::min(psg::STAGE_BYTES, std::max<size_t>(total, 4096));
+    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { fail("hipStreamCreate", e); return; }
+    if ((e = hipHostMalloc((void **)&pin, 2 * piece, hipHostMallocDefault)) != hipSuccess) { fail("hipHostMalloc", e); (void)hipStreamDestroy(st); return; }
+    if ((e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+    const size_t np = (total + piece - 1) / piece;
+    for (size_t k = 0; k <= np && !c->rc; ++k) {     // piece k is in flight while piece k-1 leaves its staging buffer
+      if (k < np) {
+        const int b = (int)(k & 1);
+        const size_t off = k * piece, n = std::min(piece, total - off);
+        if ((e = hipMemcpyAsync(pin + b * piece, (const char *)d_src + off, n, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipEventRecord(ev[b], st)) != hipSuccess) { fail("hipMemcpyAsync", e); break; }
+      }
+      if (k >= 1) {
+        const int b = (int)((k - 1) & 1);
+        const size_t off = (k - 1) * piece, n = std::min(piece, total - off);
+        if ((e = hipEventSynchronize(ev[b])) != hipSuccess) { fail("hipEventSynchronize", e); break; }
+        psg::host_copy((char *)h_dst + off, pin + b * piece, n);
+      }
+    }
+    (void)hipStreamSynchronize(st);
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
+    (void)hipHostFree(pin);
+    (void)hipStreamDestroy(st);
+  });
+  *out = c;
+  return 0;
+}
+int psg_copy_wait(psg_copy_t *c) {
+  if (!c) return 0;
+  if (c->th.joinable()) c->th.join();
+  const int rc = c->rc;
+  if (rc) set_error(c->err);
+  delete c;
+  return rc;
+}
+
 int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
   size_t f = 0, t = 0;
   PSG_HIP(hipMemGetInfo(&f, &t));
@@ -499,6 +560,7 @@ int psg_bitcopy(uint32_t *d_dst, int64_t dst_bit, const uint32_t *d_src, int64_t
   if (nbits == 0) return 0;
   i64 nwords = ((dst_bit + nbits - 1) >> 5) - (dst_bit >> 5) + 1;
   i64 src_words = (src_bit + nbits + 31) >> 5;
+  PSG_REQUIRE(nwords < (1ll << 32), "psg_bitcopy: more than 2^37 bits in one call");   // one thread per word, a launch holds < 2^32 threads
   hipLaunchKernelGGL(bitcopy_kernel, dim3((unsigned)cdiv(nwords, PSG_WG)), dim3(PSG_WG), 0, stream(), d_dst, dst_bit, d_src,
                      src_bit, nbits, src_words);
   PSG_HIP(hipGetLastError());

@@ -136,30 +136,37 @@ extern "C" int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_posi
 // BWT, i0 and gt_begin of a range from its partial suffix array (inmem_bwt_from_sa.hpp:47-83;
 // gt_begin: compute_initial_gt_bitvectors.hpp -- here simply "ranked after the range's first suffix")
 // =======================================================================================
-__global__ __launch_bounds__(PSG_WG) void psa_find_i0_kernel(const u32 *psa, i64 size, i64 *i0) {
-  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
-  if (k < size && psa[k] == 0) *i0 = k;
+// (grid-stride: a launch holds fewer than 2^32 threads, a range may hold more positions)
+__global__ __launch_bounds__(PSG_WG) void psa_find_i0_kernel(const u32 *psa, const u8 *psa_hi, i64 size, i64 *i0) {
+  for (i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x; k < size; k += (i64)gridDim.x * PSG_WG)
+    if (psa[k] == 0 && (!psa_hi || psa_hi[k] == 0)) *i0 = k;
 }
 // bwt[k] = text[beg + psa[k] - 1] (dummy 0 at i0); gt bit u = size - s for every suffix s ranked after suffix 0
-__global__ __launch_bounds__(PSG_WG) void psa_bwt_gt_kernel(const u8 *text, i64 beg, i64 size, const u32 *psa, const i64 *i0p, u8 *bwt, u32 *gt) {
-  i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
-  if (k >= size) return;
+__global__ __launch_bounds__(PSG_WG) void psa_bwt_gt_kernel(const u8 *text, i64 beg, i64 size, const u32 *psa, const u8 *psa_hi, const i64 *i0p, u8 *bwt, u32 *gt) {
   const i64 i0 = *i0p;
-  const u32 s = psa[k];
-  bwt[k] = s ? text[beg + s - 1] : 0;
-  if (gt && s && k > i0) { const i64 u = size - s; atomicOr(&gt[u >> 5], 1u << (u & 31)); }
+  for (i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x; k < size; k += (i64)gridDim.x * PSG_WG) {
+    const i64 s = (i64)psa[k] + (psa_hi ? (i64)psa_hi[k] << 32 : 0);
+    bwt[k] = s ? text[beg + s - 1] : 0;
+    if (gt && s && k > i0) { const i64 u = size - s; atomicOr(&gt[u >> 5], 1u << (u & 31)); }
+  }
 }
 
 extern "C" int psg_halfblock_from_psa(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa, uint8_t *d_bwt,
                                       int64_t *i0, uint32_t *d_gt_begin) {
-  PSG_REQUIRE(sc && sc->d_text && d_psa && d_bwt && i0 && size >= 1 && beg >= 0 && beg + size <= sc->n && size < 0x100000000ll, "psg_halfblock_from_psa");
+  PSG_REQUIRE(size < 0x100000000ll, "psg_halfblock_from_psa: a range of 2^32 positions or more needs psg_halfblock_from_psa40");
+  return psg_halfblock_from_psa40(sc, beg, size, d_psa, nullptr, d_bwt, i0, d_gt_begin);
+}
+
+extern "C" int psg_halfblock_from_psa40(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa, const uint8_t *d_psa_hi,
+                                        uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin) {
+  PSG_REQUIRE(sc && sc->d_text && d_psa && d_bwt && i0 && size >= 1 && beg >= 0 && beg + size <= sc->n && (d_psa_hi || size < 0x100000000ll), "psg_halfblock_from_psa40");
   DevBuf misc;
   if (int rc = misc.alloc(16)) return rc;
   PSG_HIP(hipMemsetAsync(misc.p, 0xFF, 16, stream()));
-  const unsigned grid = (unsigned)cdiv(size, PSG_WG);
-  hipLaunchKernelGGL(psa_find_i0_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), d_psa, size, misc.as<i64>());
+  const unsigned grid = (unsigned)std::min<i64>(cdiv(size, PSG_WG), 1 << 22);
+  hipLaunchKernelGGL(psa_find_i0_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), d_psa, d_psa_hi, size, misc.as<i64>());
   if (d_gt_begin) PSG_HIP(hipMemsetAsync(d_gt_begin, 0, (size_t)(((size + 31) >> 5) * 4), stream()));
-  hipLaunchKernelGGL(psa_bwt_gt_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), sc->d_text, beg, size, d_psa, misc.as<i64>(), d_bwt, d_gt_begin);
+  hipLaunchKernelGGL(psa_bwt_gt_kernel, dim3(grid), dim3(PSG_WG), 0, stream(), sc->d_text, beg, size, d_psa, d_psa_hi, misc.as<i64>(), d_bwt, d_gt_begin);
   PSG_HIP(hipGetLastError());
   i64 h = -1;
   if (int rc = psg::copy_d2h(&h, misc.p, 8)) return rc;

@@ -493,6 +493,31 @@ def test_subranges_merged_into_a_partial_sa(A, kind):
     d_bwt, i0, d_gt = A.halfblock_from_psa(sc, b, e - b, d_psa)
     assert i0 == want_i0 and np.array_equal(A.download(d_bwt, np.uint8, e - b), want_bwt)
     assert np.array_equal(orc.bits(A.download(d_gt, np.uint8, (e - b + 7) // 8), e - b), orc.bits(want_gt, e - b))
+    # the same as two planes (ranges of 2^32 positions or more: configs[3]'s 8 GiB half-blocks)
+    d_lo, d_hi = A.DeviceBuffer(4 * (e - b) + 16), A.DeviceBuffer(e - b + 16)
+    A.merge_run_planes(plan, 0, e - b, d_lo, d_hi)
+    assert np.array_equal(A.download(d_lo, np.uint32, e - b).astype(np.int64), want_psa) and not A.download(d_hi, np.uint8, e - b).any()
+    d_bwt, i0, d_gt = A.halfblock_from_psa(sc, b, e - b, d_lo, d_psa_hi=d_hi)
+    assert i0 == want_i0 and np.array_equal(A.download(d_bwt, np.uint8, e - b), want_bwt)
+    assert np.array_equal(orc.bits(A.download(d_gt, np.uint8, (e - b + 7) // 8), e - b), orc.bits(want_gt, e - b))
+    # values beyond 32 bits: the same sub-ranges placed at virtual offsets of 3 * 2^32 + ... inside an enclosing range
+    # (the merge never reads the text), a sub-range's own values given with a high plane as well
+    big = 3 << 32
+    hbs2 = []
+    for h, hb in enumerate(hbs):
+        d = dict(hb, beg=hb["beg"] + big * h)
+        if h == 2:
+            k = hb["size"]
+            d["psa_hi"] = A.upload(np.full(k, 5, np.uint8), pad_to=16)
+        hbs2.append(d)
+    plan2 = A.MergePlan(hbs2)
+    A.merge_run_planes(plan2, 0, e - b, d_lo, d_hi)
+    got = A.download(d_lo, np.uint32, e - b).astype(np.int64) + (A.download(d_hi, np.uint8, e - b).astype(np.int64) << 32)
+    owner = np.searchsorted(np.array(cuts[1:]) - b, want_psa, side="right")
+    assert np.array_equal(got, want_psa + big * owner + np.where(owner == 2, 5 << 32, 0))
+    out5 = A.DeviceBuffer(5 * (e - b) + 16)
+    plan2.run(0, e - b, out5)
+    assert np.array_equal(orc.sa5_to_sa(A.download(out5, np.uint8, 5 * (e - b))), got)
 
 
 def test_bits_rank1_and_memory_queries(A):
@@ -511,6 +536,23 @@ def test_bits_rank1_and_memory_queries(A):
     buf = A.upload(pa.array)                              # pinned source: one DMA, no staging
     assert np.array_equal(A.download(buf, np.uint32, 1 << 20), pa.array)
     pa.free()
+
+
+def test_background_download(A):
+    """psg_d2h_begin / psg_copy_wait: device buffers drain into pageable host arrays on worker threads while the library
+    stream runs kernels; with free_src the buffer goes back to the allocator when it is drained (in use drops)."""
+    rng = np.random.default_rng(8)
+    srcs = [rng.integers(0, 1 << 32, k, dtype=np.uint32) for k in (1, 1000, (40 << 20) // 4 + 3, (97 << 20) // 4 + 1)]
+    bufs = [A.upload(x, pad_to=16) for x in srcs]
+    in_use0 = A.mem_stats()[0]
+    dls = [A.BackgroundDownload(b, np.uint32, len(x), free_src=(i % 2 == 1)) for i, (b, x) in enumerate(zip(bufs, srcs))]
+    t = rng.integers(0, 255, 1 << 20, dtype=np.uint8)       # the library's own stream works meanwhile
+    r = A.rank_build(A.upload(t, pad_to=16), len(t))
+    r.free()
+    for dl, x in zip(dls, srcs):
+        assert np.array_equal(dl.wait(), x)
+    assert A.mem_stats()[0] <= in_use0 - srcs[3].nbytes
+    assert A.BackgroundDownload(None, np.uint8, 0).wait().size == 0
 
 
 def test_device_allocator_arena(A, gpu_lib):

@@ -466,3 +466,26 @@ def test_cli_checkpoint_resume(tmp_path, kind):
     assert out.read_bytes() == ref.read_bytes()
     assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
     assert sorted(os.listdir(ck)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rand", "sig3"])
+def test_cli_wide_nodes_and_device_sorted_pieces(tmp_path, kind):
+    """half-blocks of 2^32 symbols or more (the 8 GiB halves of configs[3]'s 16 GiB blocks): the merged node carries its
+    partial SA as two planes (psg_merge_run_planes, psg_halfblock_from_psa40) and the half-block keeps a high plane; with
+    --device-sort such a half-block is sorted in pieces that are merged the same way.  PSASCAN_TEST_WIDE_NODES forces
+    the planes at a small size; --leaf-size forces the pieces.  Same bytes as the plain path and the oracle's order."""
+    rng = np.random.default_rng(31)
+    n = 140_001
+    t = rng.integers(0, 255 if kind == "rand" else 3, n, dtype=np.uint8)
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    want = orc.suffix_array(t)
+    for extra, marker in ((["--leaf-size", "6000"], "merged on the device"), (["--device-sort", "--leaf-size", "9000"], "pieces sorted on the device")):
+        for block in (n, 50_000):
+            out = tmp_path / "x.sa5"
+            r = subprocess.run([CLI, "-m", "1G", "--block-size", str(block), "--check=500", "-v", "-o", str(out), str(f)] + extra, input="y\n",
+                               capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4", PSASCAN_TEST_WIDE_NODES="1"))
+            assert r.returncode == 0, r.stderr[-3000:]
+            assert marker in r.stderr
+            assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), want), (kind, extra, block)

@@ -197,3 +197,29 @@ def test_bench_configs2_shape_reduced(gpu_lib):
     # 6 GiB of the 16 GiB of partial SAs are resident in HBM (5 half-blocks of 1 GiB + margin), the rest streams in
     assert 0 < d["pcie"]["h2d_bytes_per_step"] < 4 * (4 << 30) and d["with_output_d2h"]["entries_received_on_host"] == 4 << 30
     assert d["roofline"]["frac"] > 0.05 and d["streamed_suffixes_per_step"] > 15 * (1 << 30)
+
+
+def test_halfblocks_of_more_than_2_pow_32_symbols(gpu_lib, tmp_path):
+    """BASELINE configs[3]'s shape in small: a 9 GiB block of DNA, two half-blocks of 4.5 GiB = more than 2^32 suffixes
+    each.  construct_sa --device-sort sorts each in three pieces, merges them with the hot path into a partial SA of
+    40-bit values in two planes (psg_merge_run_planes, psg_halfblock_from_psa40), hands it to host memory in the
+    background (psg_d2h_begin), runs pass A with a 4.5 Gi-symbol rank structure and merges 9 Gi entries; the output is
+    verified on the device (permutation sum, sampled adjacent pairs in suffix order)."""
+    import os, subprocess
+    from psascan_amd import api, extras
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 9 << 30
+    f = tmp_path / "dna.bin"
+    with open(f, "wb") as fh:
+        for k in range(9):
+            d_t = extras.gen_text(1 << 30, extras.MODE_DNA, 0, seed=70 + k)
+            api.download(d_t, np.uint8, 1 << 30).tofile(fh)
+            d_t.free()
+    api.lib().psg_trim()
+    try:
+        r = subprocess.run([os.path.join(root, "host", "construct_sa"), "-m", str(5 * n), "--block-size", str(n), "--device-sort", "--check=1024", "--discard-output", "-v", str(f)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="16"))
+    finally:
+        os.remove(f)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count("3 pieces sorted on the device") == 2 and "permutation sum ok, 0 of" in r.stderr
