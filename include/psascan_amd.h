@@ -61,6 +61,9 @@ int psg_host_free(void *h_ptr);
  * enqueued before the call is complete when it returns.                                                       */
 typedef struct psg_copy psg_copy_t;
 int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_copy_t **out);
+/* the other direction: h_src (pageable) goes up into d_dst in the background; d_dst must not be used by the
+ * library's stream until psg_copy_wait (the tail chunks of a text that stays in host memory: stream.hpp:104-106) */
+int psg_h2d_begin(void *d_dst, const void *h_src, int64_t bytes, psg_copy_t **out);
 int psg_copy_wait(psg_copy_t *copy);
 /* device memory: bytes handed out by psg_malloc right now / the highest value so far / held from the driver */
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "psg_halfblock_from_psa": (_int, [C.POINTER(SearchCtxC), _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
     "psg_merge_run_planes": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "psg_d2h_begin": (_int, [_vp, _vp, _i64, _int, C.POINTER(_vp)]),
+    "psg_h2d_begin": (_int, [_vp, _vp, _i64, C.POINTER(_vp)]),
     "psg_copy_wait": (_int, [_vp]),
     "psg_halfblock_from_psa40": (_int, [C.POINTER(SearchCtxC), _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "psg_bits_rank1": (_int, [_vp, _i64, C.POINTER(_i64), _i64, C.POINTER(_i64)]),

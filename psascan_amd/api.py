@@ -297,6 +297,23 @@ class BackgroundDownload:
         return self.array
 
 
+class BackgroundUpload:
+    """psg_h2d_begin: a host array goes up into a device buffer on a worker thread with its own stream; wait() before
+    the library's stream touches the buffer."""
+
+    def __init__(self, d_dst, array):
+        self._keep = (d_dst, np.ascontiguousarray(array))
+        h = C.c_void_p()
+        check(lib().psg_h2d_begin(_ptr(d_dst), self._keep[1].ctypes.data_as(C.c_void_p), self._keep[1].nbytes, C.byref(h)))
+        self.h = h.value
+
+    def wait(self):
+        if self.h:
+            h, self.h = self.h, None
+            check(lib().psg_copy_wait(h))
+        return self._keep[0]
+
+
 def merge_run_planes(plan, out_begin, out_count, d_lo, d_hi):
     """merged order as values of up to 40 bits in two planes (u32 low words, u8 bits 32..39)"""
     check(lib().psg_merge_run_planes(plan.h, out_begin, out_count, _ptr(d_lo), _ptr(d_hi)))

@@ -486,6 +486,30 @@ struct psg_copy {
   int rc = 0;
   std::string err;
 };
+// what a background copy needs: kept for the next one (a pinned allocation costs ~10 ms per 64 MiB, a chunked pass starts
+// one copy per chunk)
+struct CopyLane { hipStream_t st = nullptr; char *pin = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+static std::mutex g_lane_mu;
+static std::vector<CopyLane> g_lanes;
+static bool lane_acquire(CopyLane &L, hipError_t &e, const char *&what) {
+  {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (!g_lanes.empty()) { L = g_lanes.back(); g_lanes.pop_back(); return true; }
+  }
+  L = CopyLane();
+  what = "hipStreamCreate";
+  if ((e = hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)) != hipSuccess) return false;
+  what = "hipHostMalloc";
+  if ((e = hipHostMalloc((void **)&L.pin, 2 * psg::STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(L.st); return false; }
+  what = "hipEventCreate";
+  if ((e = hipEventCreateWithFlags(&L.ev[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&L.ev[1], hipEventDisableTiming)) != hipSuccess) {
+    if (L.ev[0]) (void)hipEventDestroy(L.ev[0]);
+    (void)hipHostFree(L.pin); (void)hipStreamDestroy(L.st);
+    return false;
+  }
+  return true;
+}
+static void lane_release(const CopyLane &L) { std::lock_guard<std::mutex> lk(g_lane_mu); g_lanes.push_back(L); }
 int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_copy_t **out) {
   PSG_REQUIRE(out && bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "psg_d2h_begin");
   PSG_HIP(psg::sync_stream());          // the source is complete before the worker reads it
@@ -498,13 +522,13 @@ int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_cop
     if (e != hipSuccess) { fail("hipSetDevice", e); return; }
     struct Release { void *p; ~Release() { if (p) psg::pool_free(p); } } release{free_src ? d_src : nullptr};   // the source goes back to the allocator the moment it is drained
     if (bytes == 0) return;
-    hipStream_t st = nullptr;
-    char *pin = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    const size_t total = (size_t)bytes, piece = std::min(psg::STAGE_BYTES, std::max<size_t>(total, 4096));
-    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { fail("hipStreamCreate", e); return; }
-    if ((e = hipHostMalloc((void **)&pin, 2 * piece, hipHostMallocDefault)) != hipSuccess) { fail("hipHostMalloc", e); (void)hipStreamDestroy(st); return; }
-    if ((e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+    CopyLane L;
+    const char *what = "";
+    if (!lane_acquire(L, e, what)) { fail(what, e); return; }
+    hipStream_t st = L.st;
+    char *pin = L.pin;
+    hipEvent_t *ev = L.ev;
+    const size_t total = (size_t)bytes, piece = psg::STAGE_BYTES;
     const size_t np = (total + piece - 1) / piece;
     for (size_t k = 0; k <= np && !c->rc; ++k) {     // piece k is in flight while piece k-1 leaves its staging buffer
       if (k < np) {
@@ -521,10 +545,44 @@ int psg_d2h_begin(void *h_dst, void *d_src, int64_t bytes, int free_src, psg_cop
       }
     }
     (void)hipStreamSynchronize(st);
-    if (ev[0]) (void)hipEventDestroy(ev[0]);
-    if (ev[1]) (void)hipEventDestroy(ev[1]);
-    (void)hipHostFree(pin);
-    (void)hipStreamDestroy(st);
+    lane_release(L);
+  });
+  *out = c;
+  return 0;
+}
+// the other direction: (pageable) host memory into a device buffer in the background -- the next tail chunk of a text
+// that stays in host memory goes up while the current one is streamed (stream.hpp:104-106 reads the tail from the
+// text file through async_backward_stream_reader: the same double buffering, with PCIe in place of the disk)
+int psg_h2d_begin(void *d_dst, const void *h_src, int64_t bytes, psg_copy_t **out) {
+  PSG_REQUIRE(out && bytes >= 0 && (bytes == 0 || (d_dst && h_src)), "psg_h2d_begin");
+  int dev = 0;
+  PSG_HIP(hipGetDevice(&dev));
+  psg_copy *c = new psg_copy();
+  c->th = std::thread([=]() {
+    auto fail = [&](const char *what, hipError_t e) { c->rc = PSG_EDEVICE; c->err = std::string("psg_h2d_begin worker: ") + what + ": " + hipGetErrorString(e); };
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) { fail("hipSetDevice", e); return; }
+    if (bytes == 0) return;
+    CopyLane L;
+    const char *what = "";
+    if (!lane_acquire(L, e, what)) { fail(what, e); return; }
+    hipStream_t st = L.st;
+    char *pin = L.pin;
+    hipEvent_t *ev = L.ev;
+    const size_t total = (size_t)bytes, piece = psg::STAGE_BYTES;
+    bool used[2] = {false, false};
+    size_t k = 0;
+    for (size_t off = 0; off < total && !c->rc; off += piece, ++k) {
+      const int b = (int)(k & 1);
+      const size_t n = std::min(piece, total - off);
+      if (used[b] && (e = hipEventSynchronize(ev[b])) != hipSuccess) { fail("hipEventSynchronize", e); break; }
+      psg::host_copy(pin + b * piece, (const char *)h_src + off, n);
+      if ((e = hipMemcpyAsync((char *)d_dst + off, pin + b * piece, n, hipMemcpyHostToDevice, st)) != hipSuccess ||
+          (e = hipEventRecord(ev[b], st)) != hipSuccess) { fail("hipMemcpyAsync", e); break; }
+      used[b] = true;
+    }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess && !c->rc) fail("hipStreamSynchronize", e);
+    lane_release(L);
   });
   *out = c;
   return 0;

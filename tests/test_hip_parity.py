@@ -553,6 +553,15 @@ def test_background_download(A):
         assert np.array_equal(dl.wait(), x)
     assert A.mem_stats()[0] <= in_use0 - srcs[3].nbytes
     assert A.BackgroundDownload(None, np.uint8, 0).wait().size == 0
+    # and up: psg_h2d_begin
+    ups = []
+    for x in srcs:
+        d = A.DeviceBuffer(x.nbytes + 16)
+        ups.append((A.BackgroundUpload(d, x), x))
+    r = A.rank_build(A.upload(t, pad_to=16), len(t))
+    r.free()
+    for up, x in ups:
+        assert np.array_equal(A.download(up.wait(), np.uint32, len(x)), x)
 
 
 def test_device_allocator_arena(A, gpu_lib):
