@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--block-gib", type=float, default=0.0, help="configs[2]: block size in GiB (default text/8)")
     ap.add_argument("--text", choices=["bytes", "dna", "english"], default=None, help="alphabet of the synthetic text (default: english for configs[2], bytes for configs[1])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] secondary figure and the CLI sample")
+    ap.add_argument("--bwt-hbm", action="store_true", help="configs[2]: keep the BWT and gt_begin of every half-block resident in HBM (default: pinned host memory, uploaded one half-block ahead)")
     ap.add_argument("--psa-hbm-gib", type=float, default=-1.0, help="configs[2]: GiB of partial SAs kept resident in HBM next to the pass temporaries (default: as many half-blocks as fit, sized by an untimed step)")
     ap.add_argument("--with-output-d2h", action="store_true", help="configs[2]: also time one step with the .sa5 slices copied back to the host")
     ap.add_argument("--max-chains", type=int, default=0)
@@ -440,18 +441,49 @@ def config2(args, ctx, n, block):
             pa = api.PinnedArray(he - hb, np.uint32)            # the partial SA waits in pinned host memory
             api.check(L.psg_d2h(pa.ptr, r["psa_lo"].ptr, 4 * (he - hb)))
             r["psa_lo"].free()
-            tpin += time.time() - t1
             pins.append(pa)
-            prepared[(hb, he)] = {"device": True, "psa_host": pa.array, "psa_lo": None, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
-                                  "initA": init, "keep_inputs": True}
+            ent = {"device": True, "psa_host": pa.array, "psa_lo": None, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb,
+                   "initA": init, "keep_inputs": True}
+            if not args.bwt_hbm:
+                # the sorter's other products (BWT, gt_begin) wait in pinned host memory too, as they would behind a host
+                # sorter; the step uploads them one half-block ahead of the schedule, in the background
+                gw = (he - hb + 31) // 32 + 2
+                pb, pg = api.PinnedArray(he - hb + 16, np.uint8), api.PinnedArray(gw, np.uint32)
+                api.check(L.psg_d2h(pb.ptr, r["bwt"].ptr, he - hb))
+                api.check(L.psg_d2h(pg.ptr, r["gt_begin"].ptr, min(4 * gw, r["gt_begin"].nbytes)))
+                r["bwt"].free(); r["gt_begin"].free()
+                pins += [pb, pg]
+                ent.update({"bwt": None, "gt_begin": None, "bwt_host": pb.array, "gt_host": pg.array, "keep_inputs": False})
+            tpin += time.time() - t1
+            prepared[(hb, he)] = ent
     L.psg_trim()        # the sorter's temporaries go back to the driver: the step starts from the resident inputs only
     log(f"prepared {n / 2 ** 30:.2f} GiB {args.text} text, {len(prepared)} half-blocks in {time.time() - t0:.1f}s (device sort {tsort:.1f}s, pinned alloc + D2H {tpin:.1f}s)")
 
+    order = [k for (b, mid, e) in plan for k in ((mid, e), (b, mid)) if k[1] > k[0]]     # the schedule's order of half-blocks
+
     class Replay:
         device = True
+        inflight = {}
+
+        def prefetch(self, key):
+            if args.bwt_hbm or key in self.inflight:
+                return
+            v = prepared[key]
+            d_b, d_g = api.DeviceBuffer(v["bwt_host"].nbytes), api.DeviceBuffer(v["gt_host"].nbytes)
+            self.inflight[key] = (d_b, d_g, api.BackgroundUpload(d_b, v["bwt_host"]), api.BackgroundUpload(d_g, v["gt_host"]))
 
         def __call__(self, text, beg, end, gt_tail):
-            return dict(prepared[(beg, end)])
+            r = dict(prepared[(beg, end)])
+            if not args.bwt_hbm:
+                self.prefetch((beg, end))
+                d_b, d_g, u1, u2 = self.inflight.pop((beg, end))
+                u1.wait(); u2.wait()
+                r["bwt"], r["gt_begin"] = d_b, d_g
+                k = order.index((beg, end))
+                for d in (1, 2):                                  # both halves of the next block go up during this block's passes
+                    self.prefetch(order[(k + d) % len(order)])
+            return r
+    replay = Replay()
 
     want_sum = (n * (n - 1) // 2) % (1 << 64)
     agg = {"stream_ms": 0.0, "kernel_ms": 0.0, "hist_ms": 0.0, "suffixes": 0, "launches": 0, "passes_s": 0.0, "merge_s": 0.0, "merge_kernel_ms": 0.0,
@@ -461,7 +493,7 @@ def config2(args, ctx, n, block):
     def step(timed, sink=None):
         stats, tm = [], {}
         ts = time.perf_counter()
-        ms, chk = pipeline.construct_sa5(None, block, ram_use, Replay(), args.max_chains, stats, d_text=d_text, n=n, merge="stream",
+        ms, chk = pipeline.construct_sa5(None, block, ram_use, replay, args.max_chains, stats, d_text=d_text, n=n, merge="stream",
                                          sink=sink, check_samples=4096, timings=tm)
         api.sync()
         te = time.perf_counter()
@@ -491,6 +523,7 @@ def config2(args, ctx, n, block):
         total = api.device_memory()[1]
         budget = int(args.psa_hbm_gib * 2 ** 30) if args.psa_hbm_gib > 0 else total - peak0 - (36 << 30)   # headroom: arena granules, fragmentation
         L.psg_trim()
+        placed = []
         for key in sorted(prepared, key=lambda k: -k[0]):           # rightmost half-blocks first
             v = prepared[key]
             if 4 * v["size"] + (1 << 20) > budget:
@@ -500,11 +533,34 @@ def config2(args, ctx, n, block):
             except Exception:
                 break                                               # no room after all: the rest stays in host memory
             api.check(L.psg_h2d(d.ptr, v["psa_host"].ctypes.data, 4 * v["size"]))
-            v["psa_lo"], v["psa_host"] = d, None
+            v["psa_lo"], v["psa_pinned"], v["psa_host"] = d, v["psa_host"], None
             budget -= 4 * v["size"] + (1 << 20)
-            resident += 1
+            placed.append(key)
+        # the device arena was trimmed to place them: one untimed step lets it grow back.  The steps allocate in the same
+        # order every time, so a settling step that fits means the timed steps fit; if it does not, the last partial SA
+        # placed goes back to host memory and the step is tried again.
+        while True:
+            failed = None
+            try:
+                dt = step(False)
+            except Exception as ex:
+                failed = str(ex)
+            if failed is None:
+                break
+            if not placed or "memory" not in failed.lower():
+                raise RuntimeError(failed)
+            import gc
+            gc.collect()                                             # the failed step's buffers
+            v = prepared[placed.pop()]
+            v["psa_lo"].free()
+            v["psa_lo"], v["psa_host"] = None, v["psa_pinned"]
+            for (d_b, d_g, u1, u2) in replay.inflight.values():
+                u1.wait(); u2.wait(); d_b.free(); d_g.free()
+            replay.inflight.clear()
+            L.psg_trim()
+            log(f"settling step ran out of device memory: one partial SA back to host memory ({len(placed)} resident)")
+        resident = len(placed)
         log(f"{resident} of {len(prepared)} partial SAs resident in HBM ({sum(4 * v['size'] for v in prepared.values() if v['psa_host'] is None) / 2 ** 30:.1f} GiB), the rest in pinned host memory")
-        dt = step(False)              # the device arena was trimmed to place them: one untimed step lets it grow back
         warm = max(0, warm - 1)
         log(f"settling step: {dt:.2f}s")
     for k in range(warm):
@@ -545,8 +601,9 @@ def config2(args, ctx, n, block):
         "config": {"workload": f"configs[2]: {n / 2 ** 30:.2f} GiB {'English-like text (seeded Zipfian words, sigma=28)' if args.text == 'english' else args.text + ' text'}, "
                                f"{len(plan)} blocks of {block / 2 ** 30:.2f} GiB = {len(prepared)} half-blocks on 1 GPU, whole schedule (passes A and B of every block + final merge)",
                    "text_bytes": n, "blocks": len(plan), "half_blocks": len(prepared), "block_bytes": block,
-                   "resident_in_hbm": f"text, BWT + gt bits of every half-block, merge bitvectors, {resident} of {len(prepared)} partial suffix arrays",
-                   "in_pinned_host_memory": f"{len(prepared) - resident} of {len(prepared)} partial suffix arrays (4 B/symbol), streamed during the merge",
+                   "resident_in_hbm": f"text, {'BWT + gt bits of every half-block, ' if args.bwt_hbm else ''}merge bitvectors, {resident} of {len(prepared)} partial suffix arrays",
+                   "in_pinned_host_memory": f"{len(prepared) - resident} of {len(prepared)} partial suffix arrays (4 B/symbol), streamed during the merge"
+                                            + ("" if args.bwt_hbm else "; BWT + gt_begin of every half-block (the host sorter's products), uploaded one half-block ahead of the schedule in the background"),
                    "rank_bytes_per_symbol_pass_B": round(sum(rankB) / max(1, len(rankB)), 3)},
         "gap_stream_suffixes_per_s": suff / (agg["stream_ms"] / K / 1e3),
         "gap_stream_kernel_suffixes_per_s": suff / kern_s if kern_s else None,
@@ -555,7 +612,8 @@ def config2(args, ctx, n, block):
                      "stream_partition_hist": round(agg["hist_ms"] / K, 1), "merge_total": round(1e3 * agg["merge_s"] / K, 1),
                      "merge_kernels": round(agg["merge_kernel_ms"] / K, 1), "merge_host_staging": round(agg["stage_ms"] / K, 1)},
         "pcie": {"h2d_bytes_per_step": agg["h2d"] // K, "d2h_bytes_per_step": agg["d2h"] // K,
-                 "note": "partial SAs stream in from pinned host memory during the merge; the output is checked on the device and dropped"},
+                 "h2d_halfblock_inputs_bytes_per_step": 0 if args.bwt_hbm else sum(v["bwt_host"].nbytes + v["gt_host"].nbytes for v in prepared.values()),
+                 "note": "partial SAs stream in from pinned host memory during the merge (h2d_bytes_per_step); BWT + gt_begin of the half-blocks go up in the background during the passes; the output is checked on the device and dropped"},
         "with_output_d2h": with_d2h,
         "device_memory": {"peak_in_use_gib": round(peak / 2 ** 30, 2), "reserved_gib": round(reserved / 2 ** 30, 2)},
         "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -568,12 +626,16 @@ def config2(args, ctx, n, block):
                            "note": "PCIe-bound: 4 bytes per suffix of partial SA cross the link (H2D) inside the timed merge"},
         "property_check": {"every_step": "permutation sum == n(n-1)/2 and 4096 sampled adjacent pairs per 64 Mi-entry slice in suffix order, on the device"},
     }
-    for pa in pins:
-        pa.free()
+    for (d_b, d_g, u1, u2) in replay.inflight.values():
+        u1.wait(); u2.wait(); d_b.free(); d_g.free()
+    replay.inflight.clear()
     for v in prepared.values():
-        v["bwt"].free(); v["gt_begin"].free()
+        if v.get("bwt") is not None:
+            v["bwt"].free(); v["gt_begin"].free()
         if v.get("psa_lo") is not None:
             v["psa_lo"].free()
+    for pa in pins:
+        pa.free()
     d_text.free()
     L.psg_trim()
     return res
