@@ -217,10 +217,13 @@ __device__ __forceinline__ i64 lf_core(const RankView<CNT, B> &R, const u64 *T1,
 // ---------------------------------------------------------------------------------------
 // K1 kernels
 // ---------------------------------------------------------------------------------------
+// (16 copies of the histogram, copy = lane & 15, bin-major so that the copies of a bin lie in different banks: on
+// natural-language BWTs a few symbols take most of the increments and 64 lanes hitting one LDS word serialise)
 __global__ __launch_bounds__(PSG_WG) void hist256_kernel(const u8 *bwt, i64 m, unsigned long long *out) {
-  __shared__ u32 h[256];
-  h[threadIdx.x] = 0;
+  __shared__ u32 h[256 * 16];
+  for (int k = threadIdx.x; k < 256 * 16; k += PSG_WG) h[k] = 0;
   __syncthreads();
+  const u32 cp = threadIdx.x & 15u;
   for (i64 k = ((i64)blockIdx.x * PSG_WG + threadIdx.x) * 16; k < m; k += (i64)gridDim.x * PSG_WG * 16) {
     if (k + 16 <= m) {
       uint4 v = *(const uint4 *)(bwt + k);
@@ -228,23 +231,28 @@ __global__ __launch_bounds__(PSG_WG) void hist256_kernel(const u8 *bwt, i64 m, u
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) atomicAdd(&h[(w[q] >> (8 * b)) & 255], 1u);
+        for (int b = 0; b < 4; ++b) atomicAdd(&h[(((w[q] >> (8 * b)) & 255) << 4) | cp], 1u);
     } else {
-      for (i64 j = k; j < m; ++j) atomicAdd(&h[bwt[j]], 1u);
+      for (i64 j = k; j < m; ++j) atomicAdd(&h[((u32)bwt[j] << 4) | cp], 1u);
     }
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+  u32 tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += h[(threadIdx.x << 4) | ((k + threadIdx.x) & 15)];
+  if (tot) atomicAdd(&out[threadIdx.x], (unsigned long long)tot);
 }
 
 template <int CNT, int B>
 __global__ __launch_bounds__(PSG_WG) void seg_hist_kernel(const u8 *bwt, i64 m, const u8 *code_g, u32 *seg_cnt) {
   constexpr int SEGSYM = SEG_BLOCKS * B;
-  __shared__ u32 h[CNT];
+  constexpr int CP = CNT <= 256 ? 8 : 1;            // copies of the histogram (see hist256_kernel)
+  __shared__ u32 h[CNT * CP];
   __shared__ u8 code[256];
   code[threadIdx.x] = code_g[threadIdx.x];
-  for (int k = threadIdx.x; k < CNT; k += PSG_WG) h[k] = 0;
+  for (int k = threadIdx.x; k < CNT * CP; k += PSG_WG) h[k] = 0;
   __syncthreads();
+  const u32 cp = threadIdx.x & (CP - 1);
   i64 base = (i64)blockIdx.x * SEGSYM;
   if (SEGSYM == 16 * PSG_WG && base + SEGSYM <= m && ((uintptr_t)bwt & 15) == 0) {   // whole segment: one 16-byte load per thread
     const uint4 v = ((const uint4 *)(bwt + base))[threadIdx.x];
@@ -252,19 +260,24 @@ __global__ __launch_bounds__(PSG_WG) void seg_hist_kernel(const u8 *bwt, i64 m, 
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       u32 cd = code[(w[k >> 2] >> (8 * (k & 3))) & 255u];
-      if (cd != 0xFFu) atomicAdd(&h[cd], 1u);
+      if (cd != 0xFFu) atomicAdd(&h[cd * CP + cp], 1u);
     }
   } else {
     for (int k = threadIdx.x; k < SEGSYM; k += PSG_WG) {
       i64 p = base + k;
       if (p < m) {
         u32 cd = code[bwt[p]];
-        if (cd != 0xFFu) atomicAdd(&h[cd], 1u);
+        if (cd != 0xFFu) atomicAdd(&h[cd * CP + cp], 1u);
       }
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < CNT; k += PSG_WG) seg_cnt[(i64)blockIdx.x * CNT + k] = h[k];
+  for (int k = threadIdx.x; k < CNT; k += PSG_WG) {
+    u32 tot = 0;
+#pragma unroll
+    for (int q = 0; q < CP; ++q) tot += h[k * CP + ((q + k) & (CP - 1))];
+    seg_cnt[(i64)blockIdx.x * CNT + k] = tot;
+  }
 }
 
 // thread per (group, col): serial exclusive prefix over the group's segments (in place)
