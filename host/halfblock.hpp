@@ -189,10 +189,6 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
   uint8_t code[256];
   int sigma = 0;
   for (int c = 0; c < 256; ++c) { code[c] = 0; if (present[c]) code[c] = (uint8_t)(++sigma); }   // 0 = past the end of the text
-  // the refinement reads keys further right than `reach`: a symbol that does not occur in or near the block has no
-  // code (equal keys must mean equal symbols) -- the sorter gives up on such a key and SA-IS takes over
-  uint8_t code_all[256];
-  for (int c = 0; c < 256; ++c) code_all[c] = present[c] ? code[c] : 0xFF;
   if (present[255]) throw std::runtime_error("the input contains byte 255");
   int bits = 1;
   while ((1 << bits) <= sigma) ++bits;
@@ -250,15 +246,30 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
       // Groups of equal prefixes are refined with the NEXT per_key symbols as an integer key (read straight from the
       // text), group by group and deeper and deeper -- natural language leaves ~20 suffixes per 12-symbol prefix and
       // needs 3-4 such rounds; comparing suffix pairs symbol by symbol instead made this sorter slower than SA-IS there.
+      // The key of a round is the next 8 text bytes as a big-endian integer: one unaligned load + byte swap (packing
+      // 12 five-bit codes through a table cost more than the sort it fed).  Equal bytes <=> equal symbols, and byte
+      // order is symbol order; a suffix that ends inside the 8 bytes is padded with zeros and flagged, and a sub-group
+      // that holds such a suffix is finished by plain comparison (the shorter suffix is the smaller one).
       std::vector<std::pair<uint64_t, uint32_t>> tmp;
-      auto key_at = [&](int64_t p) {
-        uint64_t k = 0;
-        for (int t = 0; t < per_key; ++t) {
-          const uint8_t cd = p + t < n ? code_all[text[p + t]] : 0;
-          if (cd == 0xFF) throw GtCapExceeded();
-          k = (k << bits) | cd;
+      bool ran_off = false;
+      auto key_at = [&](int64_t p) -> uint64_t {
+        uint64_t v = 0;
+        if (p + 8 <= n) { std::memcpy(&v, text + p, 8); return __builtin_bswap64(v); }
+        ran_off = true;
+        for (int t = 0; t < 8; ++t) v = (v << 8) | (p + t < n ? text[p + t] : 0);
+        return v;
+      };
+      // the same comparison as less_from, 8 bytes at a time while both suffixes have them
+      auto less_fast = [&](uint32_t a, uint32_t b, int64_t known) {
+        int64_t x = beg + a + known, y = beg + b + known, k = 0;
+        while (x + k + 8 <= n && y + k + 8 <= n) {
+          uint64_t p, q;
+          std::memcpy(&p, text + x + k, 8); std::memcpy(&q, text + y + k, 8);
+          if (p != q) return __builtin_bswap64(p) < __builtin_bswap64(q);
+          k += 8;
+          if (k >= cap || (budget -= 8) < 0) throw GtCapExceeded();
         }
-        return k;
+        return less_from(a, b, (int)std::min<int64_t>(known + k, 1 << 30));
       };
       std::vector<std::pair<std::pair<int64_t, int64_t>, int64_t>> stack;   // ((lo, hi), depth): kv[lo..hi) share `depth` symbols
       for (int64_t g0 = 0; g0 < m;) {
@@ -270,18 +281,25 @@ static inline bool sort_halfblock_radix(const uint8_t *text, int64_t n, int64_t 
           stack.pop_back();
           const int64_t cnt = hi - lo;
           if (cnt <= 12) {
-            std::sort(kv.begin() + lo, kv.begin() + hi, [&](uint64_t a, uint64_t b) { return less_from((uint32_t)a, (uint32_t)b, (int)std::min<int64_t>(depth, 1 << 30)); });
+            std::sort(kv.begin() + lo, kv.begin() + hi, [&](uint64_t a, uint64_t b) { return less_fast((uint32_t)a, (uint32_t)b, depth); });
             continue;
           }
           if (depth >= cap || (budget -= 4 * cnt) < 0) throw GtCapExceeded();
           tmp.resize((size_t)cnt);
+          ran_off = false;
           for (int64_t i = 0; i < cnt; ++i) { const uint32_t p = (uint32_t)kv[(size_t)(lo + i)]; tmp[(size_t)i] = {key_at(beg + (int64_t)p + depth), p}; }
+          const bool group_ran_off = ran_off;
           std::sort(tmp.begin(), tmp.end());
           for (int64_t i = 0; i < cnt; ++i) kv[(size_t)(lo + i)] = (kv[(size_t)lo] & 0xFFFFFFFF00000000ull) | tmp[(size_t)i].second;
           for (int64_t r0 = 0; r0 < cnt;) {
             int64_t r1 = r0 + 1;
             while (r1 < cnt && tmp[(size_t)r1].first == tmp[(size_t)r0].first) ++r1;
-            if (r1 - r0 > 1) stack.push_back({{lo + r0, lo + r1}, depth + per_key});
+            if (r1 - r0 > 1) {
+              bool near_end = false;
+              if (group_ran_off) for (int64_t i = r0; i < r1 && !near_end; ++i) near_end = beg + (int64_t)tmp[(size_t)i].second + depth + 8 > n;
+              if (near_end) std::sort(kv.begin() + lo + r0, kv.begin() + lo + r1, [&](uint64_t a, uint64_t b) { return less_from((uint32_t)a, (uint32_t)b, (int)std::min<int64_t>(depth, 1 << 30)); });
+              else stack.push_back({{lo + r0, lo + r1}, depth + 8});
+            }
             r0 = r1;
           }
         }

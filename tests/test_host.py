@@ -132,6 +132,35 @@ def test_lookahead_sorters_vs_definition(H, name, method):
         assert gave_up > 0             # periodic text is left to the sequential schedule
 
 
+def test_lookahead_radix_zero_bytes_and_text_end(H):
+    """the prefix-key sorter refines groups with raw 8-byte keys; a suffix that ends inside a key is padded with zeros:
+    texts made of zero bytes / with zero runs at the end must still come out in suffix order (shorter = smaller)."""
+    rng = np.random.default_rng(1)
+    cases = []
+    for n in (50, 300, 5000, 60000):
+        cases.append(rng.integers(0, 2, n, dtype=np.uint8))
+        t = rng.integers(0, 3, n, dtype=np.uint8); t[-20:] = 0; cases.append(t)
+        w = [b"the", b"of", b"and", b"a", b"\x00\x00"]
+        cases.append(np.frombuffer(b" ".join(w[i] for i in rng.integers(0, 5, n)), np.uint8)[:n].copy())
+        t = np.frombuffer((b"abcdefgh" * (n // 8 + 1))[:n], np.uint8).copy(); t[rng.integers(0, n, n // 40)] = 0; cases.append(t)
+    sorted_ok = 0
+    for t in cases:
+        n = len(t)
+        sa = orc.suffix_array(t)
+        isa = orc.inverse(sa)
+        for (b, e) in ((0, n), (n // 3, n), (n // 4, 3 * n // 4), (n - 9, n)):
+            m = e - b
+            psa, bwt, gt, i0 = np.zeros(m, np.uint32), np.zeros(m, np.uint8), np.zeros((m + 31) // 32 + 1, np.uint32), C.c_int64(-1)
+            rc = H.psh_sort_halfblock_ahead(t, n, b, e, 1, 1 << 16, psa, bwt, C.byref(i0), gt)
+            assert rc in (0, 1)
+            if rc == 0:
+                wpsa, wbwt, wi0, wgt = orc.partial_sa(t, sa, isa, b, e)
+                assert np.array_equal(psa.astype(np.int64), wpsa), (n, b, e)
+                assert np.array_equal(bwt, wbwt) and i0.value == wi0
+                sorted_ok += 1
+    assert sorted_ok >= len(cases)
+
+
 def test_lookahead_sais_linear_on_long_runs(H):
     """Text with long zero runs of varying length (zero-padded images): neither periodic nor capped, but a
     per-position bounded comparison costs O(m * run length) there (10 s for this 2 MiB half-block before the
