@@ -133,6 +133,9 @@ struct HistJob {
   bool own_excess = false;   // the job's own stand-in excess area: a carry is an error
 };
 int gap_hist_launch(HistJob &job, u32 *d_log, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex = GapExcess{nullptr, nullptr, 32}, i64 slot_base = 0);
+// two-plane log, arrays of up to 2^33 counters (one slab: gap_hist_wide_one_slab): launch only, on stream()
+bool gap_hist_wide_one_slab(i64 m);
+int gap_hist_wide_launch(HistJob &job, const u32 *log_lo, const u8 *log_hi, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex);
 int gap_hist_wait(HistJob &job, double *ms);
 
 // property check of `count` packed uint40 entries (prep.hip): acc[0] += sum of the entries (mod 2^64),

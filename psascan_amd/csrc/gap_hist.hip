@@ -591,6 +591,16 @@ int psg::gap_hist_from_log(u32 *d_log, i64 nlog, i64 m, u32 *d_gap, double *ms, 
 // slabs reading as "no entry" (one slab for blocks up to 8 Gi symbols; a separate slab-split pass cost 14 ms per 2^31
 // entries, more than a level of the partition itself).  PSG_LOG_SLAB_SHIFT makes the slabs small so that tests
 // cross several of them.
+bool psg::gap_hist_wide_one_slab(i64 m) {
+  int slab_shift = 33;
+  if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 33) slab_shift = v; }
+  return (m >> slab_shift) == 0;
+}
+int psg::gap_hist_wide_launch(HistJob &job, const u32 *log_lo, const u8 *log_hi, i64 nlog, i64 m, u32 *d_gap, bool overwrite, GapExcess ex) {
+  const Keys40 K{log_lo, log_hi, 0, (u64)0, (u64)m + 1};
+  return hist_job_launch(job, K, nlog, m, d_gap, overwrite, ex, 0);
+}
+
 int psg::gap_hist_from_wide_log(DevBuf &log_lo, DevBuf &log_hi, i64 nlog, i64 m, u32 *d_gap, double *ms, bool overwrite, GapExcess ex) {
   int slab_shift = 33;
   if (const char *e = getenv("PSG_LOG_SLAB_SHIFT")) { int v = atoi(e); if (v >= 8 && v <= 33) slab_shift = v; }

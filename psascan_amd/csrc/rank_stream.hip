@@ -987,6 +987,22 @@ struct PassArgs {
   i64 tail_begin_abs;
   u32 **log_out;
   i64 *nlog_out;
+  struct DeferredHist *defer;     // chunked pass: the histogram of a chunk's rank log runs behind the next chunk's kernel
+};
+// The partition + histogram of a chunk's rank log on the side stream, while the main stream runs the next chunk's
+// kernel (which only appends to its own log): the job, the log it reads, and where its time is reported.
+struct DeferredHist {
+  HistJob job;
+  DevBuf log_lo, log_hi;
+  bool active = false;
+  int wait(double *ms) {
+    if (!active) { if (ms) *ms = 0; return 0; }
+    active = false;
+    int rc;
+    { StreamScope sc(side_stream()); rc = gap_hist_wait(job, ms); }
+    log_lo.alloc(16); log_hi.alloc(16);
+    return rc;
+  }
 };
 static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats);
 static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats);
@@ -1045,6 +1061,12 @@ static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stat
   if (A.log_out || T <= chunk) return stream_chunk(A, h_final_rank, stats);
   psg_stream_stats acc = {};
   int64_t fin = A.rank_at_end;
+  DeferredHist deferred;
+  // Off unless PSG_HIST_OVERLAP=1.  Measured at configs[2]: the step gains 2.4 % (6.46 -> 6.31 s), but the
+  // partition's streaming traffic and its waves slow the latency-bound stream kernel by 11 % (3.63 -> 4.01 s per step),
+  // and the histogram itself stretches 3x at the occupancy the kernel leaves it -- the two do not hide behind each other.
+  const char *ov = getenv("PSG_HIST_OVERLAP");
+  const bool overlap = ov && !strcmp(ov, "1") && A.d_gap;
   for (int64_t u_lo = 0; u_lo < T; u_lo += chunk) {     // u = distance from the tail end
     int64_t u_hi = std::min<int64_t>(T, u_lo + chunk);
     psg_stream_stats st = {};
@@ -1058,12 +1080,24 @@ static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stat
     C.d_gt_out = A.d_gt_out ? A.d_gt_out + (u_lo >> 5) : nullptr;
     C.fresh = A.fresh && u_lo == 0;
     C.tail_begin_abs = A.tail_begin_abs + (T - u_hi);
+    C.defer = overlap ? &deferred : nullptr;
     int rc = stream_chunk(C, &fin, &st);
-    if (rc) return rc;
+    if (rc) { (void)deferred.wait(nullptr); return rc; }
     acc.n_chains = std::max(acc.n_chains, st.n_chains); acc.chain_len = st.chain_len;
     acc.warmup_steps = std::max(acc.warmup_steps, st.warmup_steps);
     acc.unresolved += st.unresolved; acc.rounds += st.rounds;
     acc.kernel_ms += st.kernel_ms; acc.total_ms += st.total_ms; acc.hist_ms += st.hist_ms;
+  }
+  if (deferred.active) {                                  // the last chunk's histogram, and the excess list's overflow flag after it
+    double t = 0;
+    if (int rc = deferred.wait(&t)) return rc;
+    acc.hist_ms += t; acc.total_ms += t;
+    int gbits = 32;
+    if (int rc = gap_prepare(A.d_gap, A.r->m, false, &gbits)) return rc;
+    GapExcess gex = gap_excess(A.d_gap, A.r->m, gbits);
+    u32 xflag = 0;
+    if (gex.hdr) { if (int rc = psg::copy_d2h(&xflag, gex.hdr + 2, 4)) return rc; }
+    if (xflag) { set_error("stream: excess list capacity exceeded"); return PSG_ECHECK; }
   }
   note_kernel_ms(acc.kernel_ms);
   if (h_final_rank) *h_final_rank = fin;
@@ -1115,6 +1149,10 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     const bool wide = r->m >= 0xFFFFFFFFll || getenv("PSG_LOG_WIDE") != nullptr;   // ranks need more than 32 bits (tests: forced)
     if (want_log) mode = wide ? 3 : 2;
     if (log_out) mode = 2;   // the caller wants the log itself (32-bit ranks: checked by psg_stream_gap_log)
+  }
+  double prev_hist_ms = 0;
+  if (A.defer && A.defer->active && mode != 3) {   // this chunk updates the gap array itself: the histogram still running on the side stream comes first
+    if (int rc = A.defer->wait(&prev_hist_ms)) return rc;
   }
   if (fresh && mode < 2) PSG_HIP(hipMemsetAsync(d_gap, 0, (size_t)(r->m + 1) * 4, stream()));   // the atomics need zeroes; the histogram overwrites
   // chain plan: exactly one resident wave of workgroups (a partial second wave would double the
@@ -1287,10 +1325,21 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
   } else if (mode == 2) {
     if ((rc = psg::gap_hist_from_log(log_d.as<u32>(), K * L, r->m, d_gap, &hist_ms, fresh, gex))) return rc;
     log_d.alloc(16);   // give the log back to the pool before returning
+  } else if (mode == 3 && A.defer && psg::gap_hist_wide_one_slab(r->m)) {
+    // behind the next chunk's kernel: the previous chunk's job (same side stream, its buffers) is collected first
+    if ((rc = A.defer->wait(&prev_hist_ms))) return rc;
+    std::swap(A.defer->log_lo.p, log_d.p); std::swap(A.defer->log_lo.bytes, log_d.bytes);
+    std::swap(A.defer->log_hi.p, loghi_d.p); std::swap(A.defer->log_hi.bytes, loghi_d.bytes);
+    {
+      StreamScope sc(side_stream());
+      if ((rc = psg::gap_hist_wide_launch(A.defer->job, A.defer->log_lo.as<u32>(), A.defer->log_hi.as<u8>(), K * L, r->m, d_gap, fresh, gex))) return rc;
+    }
+    A.defer->active = true;
   } else if (mode == 3) {
+    if (A.defer && (rc = A.defer->wait(&prev_hist_ms))) return rc;
     if ((rc = psg::gap_hist_from_wide_log(log_d, loghi_d, K * L, r->m, d_gap, &hist_ms, fresh, gex))) return rc;
   }
-  st.hist_ms = hist_ms;
+  st.hist_ms = hist_ms + prev_hist_ms;
   u32 xflag = 0;
   if (gex.hdr) PSG_HIP(hipMemcpyAsync(pinned_buf(3, 64), gex.hdr + 2, 4, hipMemcpyDeviceToHost, stream()));   // pinned: pageable read-backs stall
   total_tm.stop();

@@ -306,6 +306,62 @@ def test_stream_gap_wide_log_chunked_block_layout(A, monkeypatch):
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+@pytest.mark.parametrize("kind", ["rand255", "sig4z", "alla"])
+@pytest.mark.parametrize("fresh", [False, True])
+@pytest.mark.parametrize("bits", [32, 8])
+def test_stream_gap_histogram_behind_the_next_chunk(A, monkeypatch, kind, fresh, bits):
+    """chunked pass with the 40-bit log: the partition + histogram of chunk k runs on the side stream while the main
+    stream runs chunk k+1's kernel (PSG_HIST_OVERLAP=1; off by default, see DESIGN 3.2: same result either way, equal to the oracle's;
+    narrow counters send carries through the excess list from both)."""
+    monkeypatch.setenv("PSG_LOG_WIDE", "1")
+    monkeypatch.setenv("PSG_GAP_MODE", "log")
+    monkeypatch.setenv("PSG_PASS_CHUNK", "30016")
+    if bits != 32:
+        monkeypatch.setenv("PSG_GAP_COUNTER_BITS", str(bits))
+    n = 200000 if kind != "alla" else 90000
+    t = make_text(kind, n, 41)
+    b, e = 500, 500 + n // 3
+    bwt, i0, gt_in, init = _stream_case(t, b, e, e, n)
+    m, T = e - b, n - e
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[e - 1], t, e, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("PSG_HIST_OVERLAP", overlap)
+        d_gap = A.gap_array(m, fill=None if fresh else 0)
+        d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+        fin, st = A.stream_gap(r, i0, t[e - 1], d_text.at(e), T, d_gtin, init, d_gap, d_gtout, 300, fresh_gap=fresh)
+        assert fin == want_fin and st.hist_ms > 0 and st.rounds >= 2
+        assert np.array_equal(A.gap_values(d_gap, m), want_gap), (kind, fresh, bits, overlap)
+        assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
+def test_stream_gap_atomic_chunk_after_deferred_histogram(A, monkeypatch):
+    """automatic mode choice: a chunk of 2^22 suffixes goes through the log (its histogram deferred to the side
+    stream), the short last chunk updates the gap array with atomics -- it has to wait for the histogram before it"""
+    monkeypatch.setenv("PSG_LOG_WIDE", "1")
+    monkeypatch.setenv("PSG_HIST_OVERLAP", "1")
+    monkeypatch.setenv("PSG_PASS_CHUNK", str(1 << 22))
+    rng = np.random.default_rng(12)
+    m, T = 70_000, (1 << 22) + 4097
+    n = m + T
+    t = rng.integers(0, 4, n, dtype=np.uint8)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    _, bwt, i0, _ = orc.partial_sa(t, sa, isa, 0, m)
+    pos = n - np.arange(T)                                     # bit u <-> position n - u
+    gt_in = orc.packbits(np.where(pos < n, isa[np.minimum(pos, n - 1)], -1) > isa[m])
+    init = 0                                                   # the empty suffix is the smallest
+    want_gap, want_gt, want_fin = orc.stream_pass(orc.Rank(bwt), i0, t[m - 1], t, m, n, gt_in, init)
+    r = A.rank_build(A.upload(bwt, pad_to=16), m)
+    d_gap = A.gap_array(m, fill=None)
+    d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
+    fin, st = A.stream_gap(r, i0, t[m - 1], A.upload(t, pad_to=16).at(m), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, 0, fresh_gap=True)
+    assert fin == want_fin and st.hist_ms > 0
+    assert np.array_equal(A.gap_values(d_gap, m), want_gap)
+    assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
+
+
 # ------------------------------------------------------------------ excess list of the gap counters (a5, a7)
 @pytest.mark.parametrize("kind", ["alla", "sig4z", "skew", "rand255"])
 @pytest.mark.parametrize("mode", ["atomic", "log", "wide"])
