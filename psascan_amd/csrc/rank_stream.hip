@@ -954,18 +954,23 @@ template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamPar
 
 // resident workgroups per CU of the stream kernel that will be launched (occupancy API)
 template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int cpl, int *blocks) {
-  size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
+  // The occupancy API budgets 64 KiB of LDS per CU; gfx950 has 160 KiB, and a block with three superblocks (a 4 GiB
+  // block: 10 KiB of tables) was planned at 5 workgroups per CU where 6 run (measured: 56.7 -> 55.8 ms per 2^31
+  // suffixes, no second wave).  So: registers and static LDS from the API, the dynamic LDS against the real size.
+  const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   *blocks = 0;
-#define PSG_OCC(MODE_)                                                                                                       \
-  do {                                                                                                                       \
-    if (cpl == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, lds);  \
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, lds);           \
+#define PSG_OCC(MODE_)                                                                                                     \
+  do {                                                                                                                     \
+    if (cpl == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, 0);  \
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, 0);           \
   } while (0)
   if (mode == 3) PSG_OCC(3);
   else if (mode == 2) PSG_OCC(2);
   else if (mode == 1) PSG_OCC(1);
   else PSG_OCC(0);
 #undef PSG_OCC
+  const int by_lds = (int)(((size_t)160 << 10) / (lds + 2048));
+  if (*blocks > by_lds) *blocks = by_lds;
 }
 
 // everything one pass needs (the public entry points differ only in how they fill this in)
@@ -1166,6 +1171,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (blocks < 1) blocks = 4;
     if (blocks > 8) blocks = 8;
+    if (const char *e = getenv("PSG_STREAM_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 8) blocks = v; }   // experiments
     Ktarget = (i64)blocks * cus * PSG_WG * cpl;
   }
   DevBuf lo_d, hi_d, fin_d, list_d, flag_d;

@@ -356,8 +356,9 @@ def test_stream_gap_atomic_chunk_after_deferred_histogram(A, monkeypatch):
     r = A.rank_build(A.upload(bwt, pad_to=16), m)
     d_gap = A.gap_array(m, fill=None)
     d_gtout = A.zeros(4 * ((T + 31) // 32 + 1))
-    fin, st = A.stream_gap(r, i0, t[m - 1], A.upload(t, pad_to=16).at(m), T, A.upload(gt_in, pad_to=8), init, d_gap, d_gtout, 0, fresh_gap=True)
-    assert fin == want_fin and st.hist_ms > 0
+    d_text, d_gtin = A.upload(t, pad_to=16), A.upload(gt_in, pad_to=8)
+    fin, st = A.stream_gap(r, i0, t[m - 1], d_text.at(m), T, d_gtin, init, d_gap, d_gtout, 0, fresh_gap=True)
+    assert fin == want_fin and st.hist_ms > 0 and st.rounds == 2
     assert np.array_equal(A.gap_values(d_gap, m), want_gap)
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
