@@ -959,17 +959,25 @@ template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mod
   // suffixes, no second wave).  So: registers and static LDS from the API, the dynamic LDS against the real size.
   const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   *blocks = 0;
+  size_t static_lds = 8192;
 #define PSG_OCC(MODE_)                                                                                                     \
   do {                                                                                                                     \
-    if (cpl == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, 0);  \
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, 0);           \
+    hipFuncAttributes fa{};                                                                                                \
+    if (cpl == 2) {                                                                                                        \
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 2>, PSG_WG, 0);              \
+      if (hipFuncGetAttributes(&fa, (const void *)stream_kernel<CNT, B, MODE_, 2>) == hipSuccess) static_lds = fa.sharedSizeBytes; \
+    } else {                                                                                                               \
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_kernel<CNT, B, MODE_, 1>, PSG_WG, 0);              \
+      if (hipFuncGetAttributes(&fa, (const void *)stream_kernel<CNT, B, MODE_, 1>) == hipSuccess) static_lds = fa.sharedSizeBytes; \
+    }                                                                                                                      \
   } while (0)
   if (mode == 3) PSG_OCC(3);
   else if (mode == 2) PSG_OCC(2);
   else if (mode == 1) PSG_OCC(1);
   else PSG_OCC(0);
 #undef PSG_OCC
-  const int by_lds = (int)(((size_t)160 << 10) / (lds + 2048));
+  (void)hipGetLastError();
+  const int by_lds = (int)(((size_t)160 << 10) / (lds + static_lds + 256));     // + allocation granularity
   if (*blocks > by_lds) *blocks = by_lds;
 }
 
