@@ -319,7 +319,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   const bool text_on_host = opt_in.text_on_host || (double)n > 0.55 * (double)dev_total;
   if (text_on_host) {
     if (opt_in.check_samples >= 0) throw std::runtime_error("--check needs the text in HBM (not with --text-on-host / a text beyond 55 % of the device memory)");
-    opt.hierarchical = false; opt.device_sort = false;   // the device-side sorters read the text beyond a half-block's end
+    opt.device_sort = false;   // the device sorter reads the text up to its end; the leaf merging works through a window per half-block
     fprintf(stderr, "Text stays in host memory: tails are uploaded in chunks of %ld symbols\n\n", (long)opt_in.tail_chunk);
   }
   Dev d_text = text_on_host ? Dev(16) : upload(text.data(), n);
@@ -618,6 +618,24 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   double tm_upload = 0, tm_search = 0, tm_rank = 0, tm_stream = 0, tm_bv = 0, tm_merge = 0, tm_finish = 0;   // where the merging spends its time
   psg_search_ctx sc_text{};                                  // comparisons by reading on in the text (cmp_end = n)
   sc_text.d_text = d_text.as<uint8_t>(); sc_text.n = n; sc_text.cmp_end = n; sc_text.d_gt_cmp_end = nullptr; sc_text.nparts = 0;
+  // Text in host memory: the merging of a half-block's leaves sees the text through a WINDOW on the device -- the
+  // half-block and the look-ahead behind it -- addressed like the whole text (pointer to position 0 = window - begin).
+  // A comparison that would leave the window fails the call (PSG_EWINDOW: repeats longer than the look-ahead that
+  // span leaves); that half-block is then sorted in one piece on the host.
+  struct WindowExceeded {};
+  Dev text_window;
+  auto set_window = [&](int64_t hb, int64_t he) {
+    if (!text_on_host) return;
+    const int64_t wend = std::min<int64_t>(n, he + LOOKAHEAD_CAP + 4096);
+    text_window.alloc(wend - hb + 64);
+    CK(psg_h2d(text_window.p, text.data() + hb, wend - hb));
+    sc_text.d_text = text_window.as<uint8_t>() - hb;
+    sc_text.text_begin = hb; sc_text.text_end = wend;
+  };
+  auto ckw = [&](int rc, const char *what) {
+    if (rc == PSG_EWINDOW) throw WindowExceeded();
+    if (rc) throw std::runtime_error(std::string(what) + ": " + psg_last_error());
+  };
   auto upload_leaf = [&](HalfBlock &h) {
     const double tu = wclock();
     struct Acc { double &a; double t0; ~Acc() { a += wclock() - t0; } } acc{tm_upload, tu};
@@ -642,7 +660,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       sc.nparts = 1; sc.part[0].beg = c.beg; sc.part[0].size = c.size; sc.part[0].d_psa_lo = c.psa.as<uint32_t>(); sc.part[0].d_psa_hi = c.psa_hi.as<uint8_t>();
       int64_t r_end = 0;
       double tq = wclock();
-      if (e < n) CK(psg_initial_ranks(&sc, &e, 1, &r_end));
+      if (e < n) ckw(psg_initial_ranks(&sc, &e, 1, &r_end), "psg_initial_ranks");
       tm_search += wclock() - tq; tq = wclock();
       psg_rank_t *rk = nullptr;
       CK(with_memory_retry([&] { return psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk); }));
@@ -650,11 +668,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       Dev gap(4 * psg_gap_words(c.size), false);
       CK(psg_memset(gt_n.p, 0, gt_n.bytes));
       psg_stream_args a{};
-      a.rank = rk; a.block_i0 = c.i0; a.block_last_symbol = text.p[(size_t)x1 - 1]; a.d_tail = d_text.as<uint8_t>() + x1; a.tail_len = T; a.right_context = 0;
+      a.rank = rk; a.block_i0 = c.i0; a.block_last_symbol = text.p[(size_t)x1 - 1]; a.d_tail = sc_text.d_text + x1; a.tail_len = T; a.right_context = 0;
       a.d_gt_in = gt_c.as<uint32_t>(); a.rank_at_context_end = r_end; a.d_gap = gap.as<uint32_t>(); a.d_gt_out = gt_n.as<uint32_t>(); a.max_chains = max_chains;
       a.flags = PSG_GAP_UNINITIALIZED | PSG_SEARCH_ALL_STARTS; a.search = &sc; a.tail_begin_abs = x1;   // leaves sorted with a bounded look-ahead: no long repeats here
       psg_stream_stats st;
-      if (with_memory_retry([&] { return psg_stream_gap_args(&a, nullptr, &st); })) throw std::runtime_error(std::string("psg_stream_gap_args (sub-range): ") + psg_last_error());
+      ckw(with_memory_retry([&] { return psg_stream_gap_args(&a, nullptr, &st); }), "psg_stream_gap_args (sub-range)");
       psg_rank_free(rk);
       tm_stream += wclock() - tq; tq = wclock();
       ++inner_passes; inner_suffixes += T;
@@ -684,7 +702,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     tm_merge += wclock() - tq; tq = wclock();
     out.bwt.alloc(R + 16);
     out.gt.alloc(4 * gtw, true);
-    CK(psg_halfblock_from_psa40(&sc_text, b, R, out.psa.as<uint32_t>(), out.psa_hi.as<uint8_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()));
+    ckw(psg_halfblock_from_psa40(&sc_text, b, R, out.psa.as<uint32_t>(), out.psa_hi.as<uint8_t>(), out.bwt.as<uint8_t>(), &out.i0, out.gt.as<uint32_t>()), "psg_halfblock_from_psa40");
     tm_finish += wclock() - tq;
     return out;
   };
@@ -774,21 +792,32 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       H.gt_host.swap(h.gt_begin);
       H.psa_lo.swap(h.psa_lo); H.psa_hi.swap(h.psa_hi);
     };
-    if (leaves.empty()) {                                     // sequential schedule: one sort with gt bits
+    bool merged = false;
+    if (leaves.size() > 1) {
+      const size_t nl = leaves.size();
+      const int64_t p0 = inner_passes, s0 = inner_suffixes;
+      try {
+        set_window(hb, he);
+        DevNode root = build_tree(leaves, 0, nl);
+        take_root(root);
+        merged = true;
+        fprintf(stderr, "    sufsort (%s half): %zu leaves sorted ahead on the host (waited %.2fs), merged on the device in %.2fs (%ld passes, %.1f Mi suffixes streamed)\n",
+                what, nl, t_wait, wclock() - t0 - t_wait, (long)(inner_passes - p0), (inner_suffixes - s0) / 1048576.0);
+      } catch (const WindowExceeded &) {
+        fprintf(stderr, "    sufsort (%s half): a comparison between leaves ran past the text window on the device: host sorter\n", what);
+        leaves.clear();
+      }
+      text_window.release();
+    }
+    if (merged) {
+    } else if (leaves.size() == 1) {
+      from_host(*leaves[0]);
+      fprintf(stderr, "    host sufsort (%s half, sorted ahead; waited): %.2fs\n", what, t_wait);
+    } else {                                                  // sequential schedule: one sort with gt bits
       HalfBlock h;
       psa_host::sort_halfblock(text.data(), n, hb, he, gt_tail, h);
       from_host(h);
       fprintf(stderr, "    host sufsort (%s half): %.2fs (%.2f MiB/s)\n", what, wclock() - t0, H.size / 1048576.0 / std::max(wclock() - t0, 1e-9));
-    } else if (leaves.size() == 1) {
-      from_host(*leaves[0]);
-      fprintf(stderr, "    host sufsort (%s half, sorted ahead; waited): %.2fs\n", what, t_wait);
-    } else {
-      const size_t nl = leaves.size();
-      const int64_t p0 = inner_passes, s0 = inner_suffixes;
-      DevNode root = build_tree(leaves, 0, nl);
-      take_root(root);
-      fprintf(stderr, "    sufsort (%s half): %zu leaves sorted ahead on the host (waited %.2fs), merged on the device in %.2fs (%ld passes, %.1f Mi suffixes streamed)\n",
-              what, nl, t_wait, wclock() - t0 - t_wait, (long)(inner_passes - p0), (inner_suffixes - s0) / 1048576.0);
     }
     return H;
   };
@@ -821,7 +850,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       int64_t u = e - (mid + v);
       return (bool)((gt_host_of(R)[(size_t)(u >> 5)] >> (u & 31)) & 1u);
     };
-    L = make_half(2 * bid, b, mid, gt_tail_mid, "left", rs > 0 ? e : -1);
+    L = make_half(2 * bid, b, mid, gt_tail_mid, "left", rs > 0 && !text_on_host ? e : -1);   // (text on the host: e lies outside the half-block's window)
     double t0 = wclock();
     if (rs == 0) {
       DoneHalfBlock hbL = keep_half(L);
@@ -842,6 +871,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     int64_t initA = 0;                                        // rank of text[e..) among the left half's suffixes
     if (L.have_query_rank) initA = L.query_rank;              // found on the device before the partial SA left it
     else {                                                  // host search over the partial SA
+      if (L.pend) L.pend->wait();
       HalfBlock Lview;
       Lview.beg = b; Lview.size = ls; Lview.psa_lo.swap(L.psa_lo); Lview.psa_hi.swap(L.psa_hi);
       initA = psa_host::rank_by_search(text.data(), n, Lview, e);

@@ -169,7 +169,12 @@ typedef struct {
                                      NULL when cmp_end == n                                                  */
   int nparts;                     /* 1 or 2 sorted parts (half-blocks), all below cmp_end                    */
   struct { int64_t beg, size; const uint32_t *d_psa_lo; const uint8_t *d_psa_hi; } part[2];
+  int64_t text_begin, text_end;   /* 0, 0: all of text[0..n) is on the device.  Otherwise only text[text_begin ..
+                                     text_end) is (d_text still points at position 0: d_text = window - text_begin);
+                                     a comparison that would read outside fails the call with PSG_EWINDOW -- a text
+                                     that stays in host memory is searched through a window per half-block          */
 } psg_search_ctx;
+#define PSG_EWINDOW (-7)
 /* h_ranks[k] = sum over the parts of #{s in part : text[s..n) < text[h_positions[k]..n)}; positions lie at or
  * behind the end of the last part (position n: rank 0).                                                       */
 int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_positions, int64_t count, int64_t *h_ranks);

@@ -121,11 +121,15 @@ class StreamStats:
 PSG_GAP_UNINITIALIZED, PSG_FAIL_IF_UNRESOLVED, PSG_EUNRESOLVED = 1, 2, -6
 
 
-def search_ctx(d_text, n, cmp_end, d_gt_cmp_end, parts):
+def search_ctx(d_text, n, cmp_end, d_gt_cmp_end, parts, window=None):
     """psg_search_ctx: parts = [(beg, size, d_psa_lo, d_psa_hi or None)] (1 or 2 half-blocks below cmp_end);
-    d_gt_cmp_end: bit (n - j) = [text[j..) > text[cmp_end..)]."""
+    d_gt_cmp_end: bit (n - j) = [text[j..) > text[cmp_end..)].  window = (begin, end): d_text holds text[begin..end)
+    only (d_text = pointer to the window's first byte); a comparison that leaves it raises PSG_EWINDOW."""
     sc = SearchCtxC()
     sc.d_text, sc.n, sc.cmp_end, sc.d_gt_cmp_end, sc.nparts = _ptr(d_text), n, cmp_end, _ptr(d_gt_cmp_end), len(parts)
+    if window is not None:
+        sc.text_begin, sc.text_end = window
+        sc.d_text = _ptr(d_text) - window[0]
     for k, (beg, size, lo, hi) in enumerate(parts):
         sc.part[k].beg, sc.part[k].size, sc.part[k].d_psa_lo, sc.part[k].d_psa_hi = beg, size, _ptr(lo), _ptr(hi)
     sc._keep = (d_text, d_gt_cmp_end, parts)

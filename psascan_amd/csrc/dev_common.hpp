@@ -144,6 +144,7 @@ int check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i6
 
 // K8 (search.hip): enqueue the string search for npos device-resident positions; ranks land in d_rank
 int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank);
+int search_window_check();   // after the search has completed: PSG_EWINDOW if a comparison left the context's text window
 
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);

@@ -1254,6 +1254,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     if ((rc = psg::search_ranks_launch(A.search, pos_d.as<i64>(), nun, rk_d.as<i64>()))) return rc;
     PSG_HIP(hipMemcpyAsync(rk, rk_d.p, nun * 8, hipMemcpyDeviceToHost, stream()));
     PSG_HIP(psg::sync_stream());
+    if (A.search->text_end > 0 && (rc = psg::search_window_check())) return rc;
     for (i64 q = 0; q < nun; ++q) {
       const i64 k = list[(size_t)q];
       if (rk[q] < lo[k] || rk[q] > hi[k]) {   // the warm-up interval always contains the true rank

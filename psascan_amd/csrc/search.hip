@@ -25,6 +25,8 @@ struct SearchParams {
   const i64 *pos;
   i64 npos;
   i64 *rank;
+  i64 text_end;             // text[.. text_end) is readable (= n when the whole text is on the device)
+  int *fail;                // set when a comparison would have to read at or behind text_end
 };
 
 __device__ __forceinline__ u64 load8_unaligned(const u8 *p) {
@@ -50,7 +52,12 @@ __device__ __forceinline__ bool suffix_less_wave(const SearchParams &P, i64 s, i
       lcp_out = k;
       return g;
     }
-    const i64 chunk = std::min<i64>(512, std::min(rem_p, rem_s));
+    i64 chunk = std::min<i64>(512, std::min(rem_p, rem_s));
+    const i64 avail = P.text_end - (p + k);                 // p > s: the pattern side reaches the window's end first
+    if (avail < chunk) {
+      if (avail <= 0) { if (lane == 0) *P.fail = 1; lcp_out = k; return false; }
+      chunk = avail;
+    }
     const i64 off = (i64)lane * 8;
     u64 a = 0, b = 0;
     if (off + 8 <= chunk) { a = load8_unaligned(P.text + s + k + off); b = load8_unaligned(P.text + p + k + off); }
@@ -95,6 +102,21 @@ __global__ __launch_bounds__(PSG_WG) void search_kernel(SearchParams P) {
 }
 
 namespace psg {
+// one device word, set by a search that ran into the end of the text window
+static int *search_fail_flag() {
+  static int *flag = nullptr;
+  if (!flag && hipMalloc((void **)&flag, 64) != hipSuccess) { (void)hipGetLastError(); flag = nullptr; }
+  return flag;
+}
+// after the search has run (any stream order behind it): did a comparison leave the text window?
+int search_window_check() {
+  int *flag = search_fail_flag();
+  int h = 0;
+  if (!flag) return 0;
+  if (int rc = copy_d2h(&h, flag, 4)) return rc;
+  if (h) { set_error("search: a comparison ran past the end of the text window (repeats longer than the window's look-ahead)"); return PSG_EWINDOW; }
+  return 0;
+}
 // enqueue the search for npos device-resident positions; ranks land in d_rank
 int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank) {
   PSG_REQUIRE(sc && sc->d_text && sc->n > 0 && sc->cmp_end > 0 && sc->cmp_end <= sc->n && sc->nparts >= 1 && sc->nparts <= 2,
@@ -109,7 +131,15 @@ int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i6
     P.part[t] = SearchPart{sc->part[t].beg, sc->part[t].size, sc->part[t].d_psa_lo, sc->part[t].d_psa_hi};
   }
   P.pos = d_pos; P.npos = npos; P.rank = d_rank;
+  const bool windowed = sc->text_end > 0;
+  PSG_REQUIRE(!windowed || (sc->text_begin >= 0 && sc->text_begin <= sc->text_end && sc->text_end <= sc->n), "search context: bad text window");
+  for (int t = 0; windowed && t < sc->nparts; ++t)
+    PSG_REQUIRE(sc->part[t].beg >= sc->text_begin && sc->part[t].beg + sc->part[t].size <= sc->text_end, "search context: a part lies outside the text window");
+  P.text_end = windowed ? sc->text_end : sc->n;
+  P.fail = search_fail_flag();
+  if (!P.fail) { set_error("search: flag allocation failed"); return PSG_ENOMEM; }
   if (npos == 0) return 0;
+  PSG_HIP(hipMemsetAsync(P.fail, 0, 4, stream()));
   hipLaunchKernelGGL(search_kernel, dim3((unsigned)cdiv(npos, PSG_WG / 64)), dim3(PSG_WG), 0, stream(), P);
   PSG_HIP(hipGetLastError());
   return 0;
@@ -128,6 +158,7 @@ extern "C" int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_posi
   if ((rc = psg::search_ranks_launch(sc, pos.as<i64>(), count, rk.as<i64>()))) return rc;
   tm.stop();
   if ((rc = psg::copy_d2h(h_ranks, rk.p, (size_t)count * 8))) return rc;
+  if (sc->text_end > 0 && (rc = psg::search_window_check())) return rc;
   note_kernel_ms(tm.ms());
   return 0;
 }

@@ -517,6 +517,32 @@ def test_stream_gap_repetitive_text_resolves_in_one_round(A, monkeypatch, kind, 
     assert np.array_equal(orc.bits(A.download(d_gtout, np.uint8, (T + 7) // 8), T), orc.bits(want_gt, T))
 
 
+def test_search_through_a_text_window(A):
+    """psg_search_ctx.text_begin / text_end: only a window of the text is on the device (a text that stays in host
+    memory); ranks equal the whole-text search as long as no comparison leaves the window, PSG_EWINDOW otherwise."""
+    rng = np.random.default_rng(23)
+    x = rng.integers(0, 250, 30_000, dtype=np.uint8)
+    t = np.concatenate([rng.integers(0, 250, 5_000, dtype=np.uint8), x, x, rng.integers(0, 250, 20_000, dtype=np.uint8)])
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = 1_000, 40_000                                    # the part ends inside the second copy of x
+    psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+    d_psa = A.upload(psa.astype(np.uint32))
+    positions = np.array([e, e + 1, e + 777, 50_000], np.int64)
+    want = np.array([int((isa[b:e] < isa[p]).sum()) for p in positions])
+    whole = A.search_ctx(A.upload(t, pad_to=16), n, n, None, [(b, e - b, d_psa, None)])
+    assert np.array_equal(A.initial_ranks(whole, positions), want)
+    for w_end, ok in ((n, True), (70_000, True), (52_000, False)):      # lcp of text[5000..) and text[35000..) is 30 000: 35 000 + 30 000 > 52 000
+        win = A.upload(t[b:w_end], pad_to=64)
+        sc = A.search_ctx(win, n, n, None, [(b, e - b, d_psa, None)], window=(b, w_end))
+        if ok:
+            assert np.array_equal(A.initial_ranks(sc, positions), want)
+        else:
+            with pytest.raises(Exception, match="window"):
+                A.initial_ranks(sc, positions)
+
+
 # ------------------------------------------------------------------ in-memory pSAscan pieces (leaves merged on the device)
 @pytest.mark.parametrize("kind", ["rand255", "sig4z", "alla", "fib", "per3"])
 def test_subranges_merged_into_a_partial_sa(A, kind):

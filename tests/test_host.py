@@ -438,6 +438,29 @@ def test_cli_text_on_host_chunked_tails(tmp_path, kind):
 
 
 @pytest.mark.gpu
+def test_cli_text_on_host_leaves_through_a_window(tmp_path):
+    """--text-on-host with half-blocks cut into leaves: the device merges them seeing the text through a window (the
+    half-block + the look-ahead behind it, psg_search_ctx.text_begin/text_end).  A repeat that spans leaves and runs
+    past the window (X X Y with |X| = 150 000 and a half-block that ends inside the second X) makes the search give up
+    with PSG_EWINDOW; that half-block falls back to the host sorter.  The oracle's suffix array either way."""
+    rng = np.random.default_rng(17)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    t1 = rng.integers(0, 200, 120_001, dtype=np.uint8)
+    x = rng.integers(0, 250, 150_000, dtype=np.uint8)
+    t2 = np.concatenate([x, x, rng.integers(0, 250, 200_000, dtype=np.uint8)])
+    for name, t, block, expect_fallback in (("plain", t1, 40_000, False), ("repeat", t2, 400_000, True)):
+        f = tmp_path / f"{name}.bin"
+        f.write_bytes(bytes(t))
+        out = tmp_path / f"{name}.sa5"
+        r = subprocess.run([CLI, "-m", "1G", "--block-size", str(block), "--text-on-host", "--tail-chunk", "8192", "--leaf-size", "30000" if expect_fallback else "3000",
+                            "-v", "-o", str(out), str(f)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "Text stays in host memory" in r.stderr and "merged on the device" in r.stderr
+        assert ("ran past the text window" in r.stderr) == expect_fallback, r.stderr[-3000:]
+        assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t)), name
+
+
+@pytest.mark.gpu
 def test_cli_edge_inputs(tmp_path):
     """the reference's input constraints and degenerate sizes: byte 255 is fatal (initial_partial_sufsort.hpp:141-146:
     exit status 1, no output left behind), an empty file gives an empty .sa5, one- and two-symbol files work"""
