@@ -166,6 +166,19 @@ __device__ bool suffix_less(const u8 *text, i64 n, i64 a, i64 b, i64 skip) {
   return a + k >= n && b + k < n ? true : (a + k >= n && b + k >= n ? a > b : false);
 }
 
+// the same with a bound on the work: after `budget` more equal symbols the comparison stops and *spent_out is set --
+// a single thread must not run for minutes on periodic text (the caller gives up and hands over to the host sorter)
+__device__ bool suffix_less_bounded(const u8 *text, i64 n, i64 a, i64 b, i64 skip, i64 &budget, int *spent_out) {
+  i64 k = skip;
+  while (a + k < n && b + k < n) {
+    u8 x = text[a + k], y = text[b + k];
+    if (x != y) return x < y;
+    ++k;
+    if (--budget < 0) { *spent_out = 1; return false; }
+  }
+  return a + k >= n && b + k < n ? true : (a + k >= n && b + k >= n ? a > b : false);
+}
+
 // ---- refinement rounds: groups of suffixes that agree on their first d symbols are re-sorted by the next
 // per_key symbols (keys read straight from the text, so nothing depends on ranks of other positions).
 // head[k] = 1: sorted position k starts a group.
@@ -216,10 +229,12 @@ __global__ __launch_bounds__(PSG_WG) void fix_ties_kernel(const u8 *text, i64 n,
   while (e < size && !head[e]) ++e;
   if (e - k > max_group) { *too_big = 1; return; }
   atomicAdd(groups, 1ull);
+  i64 budget = (i64)1 << 22;                               // symbols this thread may compare: ~50 ms; periodic text runs out
   for (i64 a = k + 1; a < e; ++a) {
     u32 v = idx[a];
     i64 b = a - 1;
-    while (b >= k && suffix_less(text, n, beg + v, beg + idx[b], skip)) { idx[b + 1] = idx[b]; --b; }
+    while (b >= k && suffix_less_bounded(text, n, beg + v, beg + idx[b], skip, budget, too_big)) { idx[b + 1] = idx[b]; --b; }
+    if (budget < 0) return;
     idx[b + 1] = v;
   }
 }
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(PSG_WG) void find_i0_kernel(const u32 *psa, i64 siz
   if (k < size && psa[k] == 0) *i0 = k;
 }
 
-__global__ __launch_bounds__(PSG_WG) void bwt_gt_kernel(const u8 *text, i64 n, i64 beg, i64 size, const u32 *psa, const i64 *i0p, u8 *bwt, u32 *gt) {
+__global__ __launch_bounds__(PSG_WG) void bwt_gt_kernel(const u8 *text, i64 n, i64 beg, i64 size, const u32 *psa, const i64 *i0p, u8 *bwt, u32 *gt, int *too_long) {
   i64 k = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (k >= size) return;
   i64 i0 = *i0p;
@@ -238,7 +253,8 @@ __global__ __launch_bounds__(PSG_WG) void bwt_gt_kernel(const u8 *text, i64 n, i
   if (gt && s && k > i0) { i64 u = size - s; atomicOr(&gt[u >> 5], 1u << (u & 31)); }
   if (gt && k == 0) {                                     // bit u=0: position j = end
     i64 end = beg + size;
-    bool g = end < n ? suffix_less(text, n, beg, end, 0) : false;   // text[end..) > text[beg..) ?
+    i64 budget = (i64)1 << 24;                             // a range that repeats itself for longer is left to the host sorter
+    bool g = end < n ? suffix_less_bounded(text, n, beg, end, 0, budget, too_long) : false;   // text[end..) > text[beg..) ?
     if (g) atomicOr(&gt[0], 1u);
   }
 }
@@ -330,9 +346,14 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
   hipLaunchKernelGGL(fix_ties_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, head.as<u8>(), d_psa,
                      depth, 4096, misc.as<unsigned long long>(), (int *)((u8 *)misc.p + 8));
   PSG_HIP(hipGetLastError());
+  {
+    u64 h0[2];
+    if (int rc_ = psg::copy_d2h(h0, misc.p, 16)) return rc_;
+    if ((int)(h0[1] & 0xFFFFFFFF)) { set_error("psgx_sort_halfblock: an equal-prefix group is too large (text too repetitive for the prefix-key sorter)"); return PSG_ECHECK; }
+  }
   hipLaunchKernelGGL(find_i0_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_psa, size, (i64 *)((u8 *)misc.p + 16));
   if (d_gt_begin) PSG_HIP(hipMemsetAsync(d_gt_begin, 0, (size_t)(((size + 31) >> 5) * 4), stream()));
-  hipLaunchKernelGGL(bwt_gt_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, d_psa, (const i64 *)((u8 *)misc.p + 16), d_bwt, d_gt_begin);
+  hipLaunchKernelGGL(bwt_gt_kernel, dim3((unsigned)cdiv(size, PSG_WG)), dim3(PSG_WG), 0, stream(), d_text, n, beg, size, d_psa, (const i64 *)((u8 *)misc.p + 16), d_bwt, d_gt_begin, (int *)((u8 *)misc.p + 8));
   PSG_HIP(hipGetLastError());
   u64 h[4];
   if (int rc_ = psg::copy_d2h(h, misc.p, (size_t)(32))) return rc_;
@@ -362,7 +383,10 @@ __global__ __launch_bounds__(PSG_WG) void sa5_order_kernel(const u8 *text, i64 n
   if (t >= samples || cnt < 2) return;
   i64 k = (i64)(splitmix64(seed + (u64)t) % (u64)(cnt - 1));
   i64 a = (i64)load_u40(sa5 + 5 * k), b = (i64)load_u40(sa5 + 5 * (k + 1));
-  if (a >= n || b >= n || a == b || !suffix_less(text, n, a, b, 0)) atomicAdd(bad, 1ull);
+  if (a >= n || b >= n || a == b) { atomicAdd(bad, 1ull); return; }
+  i64 budget = (i64)1 << 24;                               // a sampled pair that agrees on 16 Mi symbols is not followed further (periodic text)
+  int spent = 0;
+  if (!suffix_less_bounded(text, n, a, b, 0, budget, &spent) && !spent) atomicAdd(bad, 1ull);
 }
 int psg::check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i64 samples, u64 seed, unsigned long long *d_acc) {
   if (count <= 0) return 0;

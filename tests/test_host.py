@@ -399,17 +399,20 @@ def test_cli_device_sort_extension(tmp_path):
     """--device-sort (NOT the default placement): half-blocks sorted by the bench's device sorter; periodic text makes it
     give up and fall back to the host sorter.  Same bytes as the default path either way."""
     rng = np.random.default_rng(5)
-    for name, t in (("rand", rng.integers(0, 200, 300_000, dtype=np.uint8)), ("per", np.frombuffer((b"abcd" * 50_000), np.uint8).copy())):
+    per2 = np.frombuffer(b"\x00\x03" * 11_860, np.uint8).copy()     # found by tools/fuzz_cli.py: a short periodic range used to keep ONE
+    per2[20_000] = 9                                                # device thread comparing for minutes (groups below the size limit)
+    for name, t in (("rand", rng.integers(0, 200, 300_000, dtype=np.uint8)), ("per", np.frombuffer((b"abcd" * 50_000), np.uint8).copy()), ("per2", per2)):
         f = tmp_path / f"{name}.bin"
         f.write_bytes(bytes(t))
         outs = []
         for extra in ([], ["--device-sort"]):
             out = tmp_path / f"{name}{len(extra)}.sa5"
-            r = subprocess.run([CLI, "-m", "1G", "--block-size", "100000", "--check=300", "-v", "-o", str(out), str(f)] + extra, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([CLI, "-m", "1G", "--block-size", "8499" if name == "per2" else "100000", "--check=300", "-v", "-o", str(out), str(f)] + extra,
+                               capture_output=True, text=True, timeout=120)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append(out.read_bytes())
             if extra:
-                assert ("device sufsort" in r.stderr) and (("gave up" in r.stderr) == (name == "per"))
+                assert ("device sufsort" in r.stderr) and (("gave up" in r.stderr) == (name != "rand"))
         assert outs[0] == outs[1]
         assert np.array_equal(orc.sa5_to_sa(np.frombuffer(outs[0], np.uint8)), orc.suffix_array(t))
 
