@@ -1,5 +1,6 @@
-"""Randomised end-to-end check of host/construct_sa against the oracle's suffix array (run on a GPU box):
-    python tools/fuzz_cli.py [cases] [seed]
+"""Randomised end-to-end check of host/construct_sa against the oracle's suffix array (run on a GPU box, from the
+repository root; test infrastructure -- it uses the oracle -- but not collected by pytest):
+    python tests/fuzz_cli.py [cases] [seed] [first case] [max symbols]
 Random texts (alphabets, runs, repeats, zero bytes), random block / leaf sizes, fan-outs and modes."""
 import os, subprocess, sys, tempfile
 import numpy as np

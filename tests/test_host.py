@@ -399,7 +399,7 @@ def test_cli_device_sort_extension(tmp_path):
     """--device-sort (NOT the default placement): half-blocks sorted by the bench's device sorter; periodic text makes it
     give up and fall back to the host sorter.  Same bytes as the default path either way."""
     rng = np.random.default_rng(5)
-    per2 = np.frombuffer(b"\x00\x03" * 11_860, np.uint8).copy()     # found by tools/fuzz_cli.py: a short periodic range used to keep ONE
+    per2 = np.frombuffer(b"\x00\x03" * 11_860, np.uint8).copy()     # found by tests/fuzz_cli.py: a short periodic range used to keep ONE
     per2[20_000] = 9                                                # device thread comparing for minutes (groups below the size limit)
     for name, t in (("rand", rng.integers(0, 200, 300_000, dtype=np.uint8)), ("per", np.frombuffer((b"abcd" * 50_000), np.uint8).copy()), ("per2", per2)):
         f = tmp_path / f"{name}.bin"
