@@ -84,7 +84,7 @@ def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True, device_
     return {"value": n / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2), "output_check": "permutation sum ok, 0 sampled pairs out of order",
             "device_memory": peak[0] if peak else None, "leaf_merging": inner[0] if inner else None,
             "sample": f"{sample_mib} MiB {'English-like text' if english else 'uniform bytes 0..254'} from a file, default -m (646 MiB blocks), "
-                      + ("half-blocks sorted on the device (--device-sort, not the reference's placement)" if device_sort else f"half-blocks sorted on {threads} host threads as 2 MiB leaves and merged on the device")
+                      + ("half-blocks sorted on the device (--device-sort, not the reference's placement)" if device_sort else f"half-blocks sorted on {threads} host threads as 1 MiB leaves and merged on the device")
                       + ", .sa5 written to a file; wall time of the child process"}
 
 

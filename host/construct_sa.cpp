@@ -8,7 +8,7 @@
 //                                 adjacent pairs per slice in suffix order); failure = exit status 1
 //                --discard-output produce the .sa5 bytes (they reach host memory) but write no file
 //                --leaf-size N / --fanout F / --no-device-merge
-//                                 half-blocks are suffix-sorted as leaves of <= N symbols on the host cores (2 MiB:
+//                                 half-blocks are suffix-sorted as leaves of <= N symbols on the host cores (1 MiB:
 //                                 the sort stays in the caches) and merged on the device, F sub-ranges at a time --
 //                                 the in-memory pSAscan of the reference (inmem_psascan.hpp:64-304) with the GPU as
 //                                 the merger
@@ -505,15 +505,17 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // ---- look-ahead sorter: LEAVES on all host cores, right to left (the order the schedule needs them).
   // A half-block larger than the leaf size is cut into leaves that ARE suffix-sorted on the host; their partial
   // SAs are merged on the device with the hot path itself -- the reference's in-memory pSAscan does the same with
-  // max_threads sub-blocks per block (inmem_psascan.hpp:64-304).  Small leaves stay inside the host caches (2 MiB
-  // leaves sort at ~50 MB/s per core, 1 GiB half-blocks at ~7), and the merging is what the GPU is fast at.
+  // max_threads sub-blocks per block (inmem_psascan.hpp:64-304).  Small leaves stay inside the host caches (a 1 GiB
+  // half-block sorts at ~7 MB/s per core, 1-2 MiB leaves at 18-30), and the merging is what the GPU is fast at.  1 MiB
+  // balances the two sides on a 16-thread box: 4 GiB of English-like text in 13.2 s with 2 MiB leaves (device busy
+  // 6.4 s), 11.95 s with 1 MiB (9.1 s), 15.3 s with 512 KiB (12.5 s: the device is the bound).
   // Comparisons that run past a leaf's end are decided by reading on in the text, which is in host memory, instead
   // of by gt bits of what lies to the right (initial_partial_sufsort.hpp:61-80) -- so a leaf depends on nothing.  A
   // leaf whose comparisons run longer than LOOKAHEAD_CAP symbols (periodic text) fails; its half-block is then sorted
   // in one piece in the sequential schedule, with gt bits from the streaming passes, as in the reference.
   const int64_t LOOKAHEAD_CAP = 1 << 16;
   const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD") && !opt.device_sort;
-  const int64_t leaf_size = opt.leaf_size > 0 ? opt.leaf_size : ((int64_t)2 << 20);
+  const int64_t leaf_size = opt.leaf_size > 0 ? opt.leaf_size : ((int64_t)1 << 20);
   struct Task { int64_t beg, end; };
   std::vector<Task> tasks;                                   // in the order the schedule consumes them
   std::vector<std::vector<int64_t>> half_tasks((size_t)(2 * n_blocks));   // half id -> its task ids, LEFT to RIGHT
