@@ -223,3 +223,14 @@ def test_halfblocks_of_more_than_2_pow_32_symbols(gpu_lib, tmp_path):
         os.remove(f)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stderr.count("3 pieces sorted on the device") == 2 and "permutation sum ok, 0 of" in r.stderr
+
+
+def test_all_modes_write_the_same_sa5(gpu_lib):
+    """256 MiB of English-like text in 6 blocks through construct_sa in five modes -- default (host leaves merged on the
+    device), --text-on-host (tails in chunks, leaves through a text window), --device-sort, --spill-psa + --checkpoint,
+    --no-device-merge (half-blocks sorted whole on host threads): the .sa5 files are byte-identical (the first of them
+    is what the reference's hashes pin at smaller sizes, tests/test_host.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_modes.py"), "256", "english"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
