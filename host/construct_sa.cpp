@@ -92,7 +92,7 @@ static void usage(int status) {
          "      --discard-output    do everything but write the output file (extension)\n"
          "      --spill-psa         partial suffix arrays in part files GAPFILE.psa.* instead of host\n"
          "                          memory (extension)\n"
-         "      --leaf-size=N       half-blocks larger than N (default 2Mi) are cut into leaves of at most N\n"
+         "      --leaf-size=N       half-blocks larger than N (default 1Mi) are cut into leaves of at most N\n"
          "                          symbols that are suffix-sorted on the host and merged on the device\n"
          "      --fanout=F          sub-ranges merged per step of that merging (default 4)\n"
          "      --no-device-merge   sort every half-block in one piece on the host (extension)\n"
@@ -209,14 +209,30 @@ struct DoneHalfBlock {
     keep_part = o.keep_part;
   }
   void spill(const std::string &prefix) {
-    if (!part_file.empty()) return;     // already on disk (checkpoint)
+    const std::string want = prefix + ".psa." + std::to_string(beg);
+    if (!part_file.empty()) {           // already on disk: under this prefix, or under another one (--spill-psa, then --checkpoint)
+      if (part_file == want) return;
+      if (map) { munmap(map, map_bytes); map = nullptr; }
+      if (rename(part_file.c_str(), want.c_str()) != 0) {   // another file system: copy
+        FILE *in = fopen(part_file.c_str(), "rb"), *o = fopen(want.c_str(), "wb");
+        bool ok = in && o;
+        std::vector<char> buf((size_t)1 << 22);
+        for (size_t got; ok && (got = fread(buf.data(), 1, buf.size(), in)) > 0;) ok = fwrite(buf.data(), 1, got, o) == got;
+        if (in) { ok = !ferror(in) && ok; fclose(in); }
+        if (o) ok = fclose(o) == 0 && ok;
+        if (!ok) { remove(want.c_str()); throw std::runtime_error("cannot move the part file " + part_file + " to " + want); }
+        remove(part_file.c_str());
+      }
+      part_file = want;
+      return;
+    }
     settle();
     part_file = prefix + ".psa." + std::to_string(beg);
     FILE *f = fopen(part_file.c_str(), "wb");
     bool ok = f && fwrite(psa_lo.data(), 4, (size_t)size, f) == (size_t)size;
     part_has_hi = !psa_hi.empty();
     if (ok && part_has_hi) ok = fwrite(psa_hi.data(), 1, (size_t)size, f) == (size_t)size;
-    if (f) ok = fclose(f) == 0 && ok;
+    if (f) { ok = fflush(f) == 0 && fsync(fileno(f)) == 0 && ok; ok = fclose(f) == 0 && ok; }   // on the disk before a manifest names it
     if (!ok) throw std::runtime_error("cannot write the part file " + part_file);
     psa_host::PsaVec().swap(psa_lo);
     psa_host::PsaHiVec().swap(psa_hi);
@@ -231,6 +247,22 @@ struct DoneHalfBlock {
   }
   const uint32_t *lo() const { return map ? (const uint32_t *)map : psa_lo.data(); }
   const uint8_t *hi() const { return map ? (part_has_hi ? (const uint8_t *)map + 4 * (size_t)size : nullptr) : (psa_hi.empty() ? nullptr : psa_hi.data()); }
+};
+
+struct RankGuard {     // a rank structure is hundreds of MiB of HBM: freed on every path out of its scope
+  psg_rank_t *r = nullptr;
+  RankGuard() {}
+  RankGuard(const RankGuard &) = delete;
+  RankGuard &operator=(const RankGuard &) = delete;
+  ~RankGuard() { reset(); }
+  void reset() { if (r) psg_rank_free(r); r = nullptr; }
+};
+struct PlanGuard {
+  psg_merge_plan_t *p = nullptr;
+  PlanGuard() {}
+  PlanGuard(const PlanGuard &) = delete;
+  PlanGuard &operator=(const PlanGuard &) = delete;
+  ~PlanGuard() { if (p) psg_merge_plan_free(p); }
 };
 
 struct MappedFile {   // read-only view of the input (the page cache is the host copy of the text)
@@ -342,7 +374,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   auto write_file = [&](const std::string &fn, const void *data, size_t bytes) {
     FILE *f = fopen(fn.c_str(), "wb");
     bool ok = f && fwrite(data, 1, bytes, f) == bytes;
-    if (f) ok = fclose(f) == 0 && ok;
+    if (f) { ok = fflush(f) == 0 && fsync(fileno(f)) == 0 && ok; ok = fclose(f) == 0 && ok; }
     if (!ok) throw std::runtime_error("cannot write the checkpoint file " + fn);
   };
   auto read_file = [&](const std::string &fn, void *data, size_t bytes) {
@@ -350,6 +382,17 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     bool ok = f && fread(data, 1, bytes, f) == bytes;
     if (f) fclose(f);
     if (!ok) throw std::runtime_error("cannot read the checkpoint file " + fn);
+  };
+  // cheap fingerprint of the text (256 sampled pages): an edited input of the same length does not resume
+  auto text_fingerprint = [&]() -> uint64_t {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+    const int64_t pages = 256, psz = 4096;
+    for (int64_t k = 0; k < pages; ++k) {
+      const int64_t off = n <= psz ? 0 : (int64_t)((__int128)(n - psz) * k / (pages - 1));
+      const int64_t len = std::min<int64_t>(psz, n - off);
+      for (int64_t i = 0; i < len; ++i) { h ^= text.p[off + i]; h *= 1099511628211ull; }
+    }
+    return h;
   };
   size_t ck_saved = 0;                                       // half-blocks already on disk
   auto checkpoint_block = [&](int64_t bid) {                 // after block bid: hbs, gt_cur are its results
@@ -372,11 +415,13 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const std::string mf = ck_prefix + ".manifest", tmp = mf + ".tmp";
     FILE *f = fopen(tmp.c_str(), "w");
     if (!f) throw std::runtime_error("cannot write " + tmp);
-    fprintf(f, "psascan-mi355x-checkpoint 1\nn %ld block %ld ram %ld\nnext_block %ld\nhalfblocks %zu\n", (long)n, (long)max_block_size, (long)ram_use, (long)(bid - 1), hbs.size());
+    fprintf(f, "psascan-mi355x-checkpoint 2\nn %ld block %ld ram %ld fp %lx\nnext_block %ld\nhalfblocks %zu\n", (long)n, (long)max_block_size, (long)ram_use,
+            (unsigned long)text_fingerprint(), (long)(bid - 1), hbs.size());
     for (const DoneHalfBlock &h : hbs) fprintf(f, "%ld %ld %d %ld\n", (long)h.beg, (long)h.size, (int)h.part_has_hi, (long)(h.mbv.p ? h.mbv.bytes : 0));
     bool ok = fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = fclose(f) == 0 && ok;
     if (!ok || rename(tmp.c_str(), mf.c_str()) != 0) throw std::runtime_error("cannot write " + mf);
+    { int dfd = open(opt.checkpoint_dir.c_str(), O_RDONLY); if (dfd >= 0) { (void)fsync(dfd); close(dfd); } }   // the rename itself
     remove((ck_prefix + ".gt." + std::to_string(bid + 1)).c_str());
     if (g_verbose) fprintf(stderr, "    checkpoint: %.2fs\n", wclock() - t1);
   };
@@ -393,11 +438,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     mkdir(opt.checkpoint_dir.c_str(), 0777);
     FILE *f = fopen((ck_prefix + ".manifest").c_str(), "r");
     if (f) {
-      long mn = -1, mb = -1, mr = -1, next = -2; size_t cnt = 0; int ver = 0;
-      bool ok = fscanf(f, "psascan-mi355x-checkpoint %d n %ld block %ld ram %ld next_block %ld halfblocks %zu", &ver, &mn, &mb, &mr, &next, &cnt) == 6 && ver == 1;
-      if (ok && (mn != (long)n || mb != (long)max_block_size || mr != (long)ram_use)) {
+      long mn = -1, mb = -1, mr = -1, next = -2; size_t cnt = 0; int ver = 0; unsigned long fp = 0;
+      bool ok = fscanf(f, "psascan-mi355x-checkpoint %d n %ld block %ld ram %ld fp %lx next_block %ld halfblocks %zu", &ver, &mn, &mb, &mr, &fp, &next, &cnt) == 7 && ver == 2;
+      if (ok && (mn != (long)n || mb != (long)max_block_size || mr != (long)ram_use || fp != (unsigned long)text_fingerprint())) {
         fclose(f);
-        throw std::runtime_error("the checkpoint in " + opt.checkpoint_dir + " belongs to another run (text length, block size or memory budget differ)");
+        throw std::runtime_error("the checkpoint in " + opt.checkpoint_dir + " belongs to another run (text, block size or memory budget differ)");
       }
       for (size_t k = 0; ok && k < cnt; ++k) {
         long hb = 0, hs = 0, mv = 0; int hh = 0;
@@ -664,7 +709,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       double tq = wclock();
       if (e < n) ckw(psg_initial_ranks(&sc, &e, 1, &r_end), "psg_initial_ranks");
       tm_search += wclock() - tq; tq = wclock();
-      psg_rank_t *rk = nullptr;
+      RankGuard rkg;
+      psg_rank_t *&rk = rkg.r;
       CK(with_memory_retry([&] { return psg_rank_build(c.bwt.as<uint8_t>(), c.size, 0, &rk); }));
       tm_rank += wclock() - tq; tq = wclock();
       Dev gap(4 * psg_gap_words(c.size), false);
@@ -675,7 +721,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       a.flags = PSG_GAP_UNINITIALIZED | PSG_SEARCH_ALL_STARTS; a.search = &sc; a.tail_begin_abs = x1;   // leaves sorted with a bounded look-ahead: no long repeats here
       psg_stream_stats st;
       ckw(with_memory_retry([&] { return psg_stream_gap_args(&a, nullptr, &st); }), "psg_stream_gap_args (sub-range)");
-      psg_rank_free(rk);
+      rkg.reset();
       tm_stream += wclock() - tq; tq = wclock();
       ++inner_passes; inner_suffixes += T;
       mbv[(size_t)i].alloc(4 * ((c.size + T + 31) / 32 + 2), true);
@@ -690,7 +736,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     std::vector<psg_hb_desc> desc((size_t)f);
     for (int i = 0; i < f; ++i)
       desc[(size_t)i] = psg_hb_desc{ch[(size_t)i].beg - b, ch[(size_t)i].size, ch[(size_t)i].psa.as<uint32_t>(), ch[(size_t)i].psa_hi.as<uint8_t>(), i + 1 < f ? mbv[(size_t)i].as<uint32_t>() : nullptr};
-    psg_merge_plan_t *plan = nullptr;
+    PlanGuard pg;
+    psg_merge_plan_t *&plan = pg.p;
     CK(psg_merge_plan_create(desc.data(), f, &plan));
     DevNode out;
     out.beg = b; out.size = R;
@@ -698,7 +745,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const bool wide = R >= wide_from;
     if (wide) out.psa_hi.alloc(R + 16);
     int mrc = wide ? psg_merge_run_planes(plan, 0, R, out.psa.as<uint32_t>(), out.psa_hi.as<uint8_t>()) : psg_merge_run_u32(plan, 0, R, out.psa.as<uint32_t>());
-    psg_merge_plan_free(plan);
+    psg_merge_plan_free(plan); plan = nullptr;
     if (mrc) throw std::runtime_error(std::string("merge of sub-ranges: ") + psg_last_error());
     ch.clear();                                               // the children's arrays are dead
     tm_merge += wclock() - tq; tq = wclock();
@@ -866,7 +913,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     Dev &d_lbwt = L.bwt, &d_rbwt = R.bwt, &d_rgt = R.gt, &d_lgt = L.gt;
     // ---- pass A (partial_sufsort.hpp:403-414)
     t0 = wclock();
-    psg_rank_t *rankL = nullptr;
+    RankGuard rankLg, rankBg;
+    psg_rank_t *&rankL = rankLg.r;
     CK(with_memory_retry([&] { return psg_rank_build(d_lbwt.as<uint8_t>(), ls, 0, &rankL); }));
     log_phase("Construct rank (left half, device)", t0, ls);
     Dev gapA(4 * psg_gap_words(ls), false), gtA(4 * ((rs + 31) / 32 + 2), true);   // fresh gap array: PSG_GAP_UNINITIALIZED
@@ -887,7 +935,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}}, &st);
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
-    psg_rank_free(rankL);
+    rankLg.reset();
     Dev bvA(4 * ((bs + 31) / 32 + 2), true);
     int64_t nb = 0;
     CK(psg_gap_to_bitvector(gapA.as<uint32_t>(), ls, bvA.as<uint32_t>(), bs, &nb));
@@ -912,7 +960,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     log_phase("Merge BWTs of half-blocks (device)", t0, bs);
     // ---- pass B (:500-514)
     t0 = wclock();
-    psg_rank_t *rankB = nullptr;
+    psg_rank_t *&rankB = rankBg.r;
     CK(with_memory_retry([&] { return psg_rank_build(d_bbwt.as<uint8_t>(), bs, 0, &rankB); }));
     d_bbwt.release();
     log_phase("Construct rank (block, device)", t0, bs);
@@ -923,7 +971,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi, &hbR}}, &st);
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
-    psg_rank_free(rankB);
+    rankBg.reset();
     CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
     CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
     // ---- split (:536-542)
@@ -970,7 +1018,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   if (!sctx.ok) throw std::runtime_error("write failed on " + out_fn);
   if (mrc) throw std::runtime_error(std::string("psg_merge_stream: ") + psg_last_error());
   if (sctx.entries != n) throw std::runtime_error("merge produced a wrong number of entries");
-  if (out) fclose(out);
+  if (out) {   // the last buffer of the .sa5 reaches the disk here: a failure keeps the checkpoint and exits non-zero
+    const bool flushed = fflush(out) == 0 && fsync(fileno(out)) == 0;
+    const bool closed = fclose(out) == 0;
+    out = nullptr;
+    if (!flushed || !closed) throw std::runtime_error("write failed on " + out_fn);
+  }
   log_phase("merge + write", t0, 5 * n);
   if (g_verbose) fprintf(stderr, "      slices=%ld merge kernels=%.1fms staging=%.1fms sink=%.1fms h2d=%.1fMiB d2h=%.1fMiB\n", (long)ms.slices, ms.kernel_ms, ms.stage_ms, ms.sink_ms, ms.h2d_bytes / 1048576.0, ms.d2h_bytes / 1048576.0);
   if (opt.check_samples >= 0) {

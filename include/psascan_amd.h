@@ -269,6 +269,28 @@ int psg_merge_run_planes(const psg_merge_plan_t *plan, int64_t out_begin, int64_
 int psg_halfblock_from_psa40(const psg_search_ctx *sc, int64_t beg, int64_t size, const uint32_t *d_psa_lo, const uint8_t *d_psa_hi,
                              uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin);
 
+/* ---- the merging half of the in-memory pSAscan in batches (inmem_psascan.hpp:64-304: max_threads sub-blocks are
+ *      suffix-sorted, then merged by streaming; initial_partial_sufsort.hpp:61-319 for the sub-block sorts).  The host
+ *      cores sort many small LEAVES of the range [range_beg, range_beg + range_size) -- leaf l = text positions
+ *      [h_leaf_beg[l], h_leaf_beg[l+1]), ordered as suffixes of the WHOLE text -- and hand over only their partial
+ *      SAs: d_leaf_psa holds them back to back in text order (entry k of leaf l at index h_leaf_beg[l] - range_beg + k),
+ *      positions relative to the leaf's begin, psa_bytes = 2 (leaves of at most 65 536 positions) or 4 bytes each.
+ *      The device derives BWT / i0 / gt bits of every leaf and merges neighbours pairwise, level by level, every
+ *      level in ONE launch sequence for all its pairs (one rank structure over the level's BWT array, one stream
+ *      kernel launch, one histogram, one merge).  Results as from psg_merge_run_u32 + psg_halfblock_from_psa: the
+ *      range's partial SA (u32, relative to range_beg; range_size < 2^32 - 16), BWT (dummy 0 at *i0), i0, gt_begin
+ *      (bit u <-> position range_beg + range_size - u).  sc: the text (comparison end = n; optionally a window).
+ *      PSG_EWINDOW: a comparison left the text window; PSG_EUNRESOLVED: a comparison between leaves exceeded its
+ *      budget of 2^20 symbols (long repeats across leaves) -- the caller sorts that range another way.            */
+typedef struct {
+  int64_t levels, passes, suffixes;     /* tree levels, pair merges, tail suffixes streamed over all levels */
+  double prepare_ms, rank_ms, search_ms, stream_ms, hist_ms, bitvector_ms, merge_ms;   /* HIP events, summed over the levels */
+  double total_ms;                      /* wall time of the call */
+} psg_leaf_merge_stats;
+int psg_merge_leaves(const psg_search_ctx *sc, int64_t range_beg, int64_t range_size, const int64_t *h_leaf_beg, int64_t n_leaves,
+                     const void *d_leaf_psa, int psa_bytes, uint32_t *d_psa_out, uint8_t *d_bwt_out, int64_t *i0, uint32_t *d_gt_begin_out,
+                     psg_leaf_merge_stats *stats);
+
 /* ---- merge<T> with the partial suffix arrays in HOST memory.  The reference keeps every partial SA in part files
  *      (io/distributed_file.hpp:58-67) and streams them back during the merge (merge.hpp:72-81, 143; parts
  *      deleted as consumed, distributed_file.hpp:159-171); here they stay where the host sorter left them and

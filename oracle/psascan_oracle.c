@@ -264,6 +264,40 @@ void orc_merge(int H, const i64 *beg, const i64 *size, const i64 *const *psa,
 }
 
 /* ------------------------------------------------------------------------- */
+/* Chain start ranks (K8): number of suffixes of the block [bb,be) that are    */
+/* smaller than text[p..n), found by binary search over the block's partial SA */
+/* with a string comparison that may only read block text and that decides a   */
+/* comparison reaching `cmp_end` (>= be) by the gt bit of the position the     */
+/* pattern has reached: em_compute_initial_ranks.hpp:54-76 (lcp_compare: the   */
+/* block suffix runs into block_end, gt w.r.t. block_end decides) and          */
+/* :321-363 (lcp_compare_2: text up to tail_begin is read, then gt w.r.t.      */
+/* tail_begin).  gt_cmp_end bit u <-> position n - u is NOT used here: the     */
+/* array is indexed like every gt array of this file, u = hi - j with hi = n.  */
+/* A pattern that ends before the comparison is decided is the smaller one     */
+/* (:69-71 "pat_beg + pat_length >= text_length -> -1").                       */
+/* ------------------------------------------------------------------------- */
+i64 orc_initial_rank(const u8 *text, i64 n, i64 bb, i64 be, const i64 *psa, i64 cmp_end, const u8 *gt_cmp_end, i64 p) {
+  if (p >= n) return 0;                               /* :180-183: the empty suffix is the smallest */
+  i64 lo = 0, hi = be - bb;                           /* answer in [lo, hi] */
+  while (lo < hi) {
+    i64 mid = (lo + hi) / 2, s = bb + psa[mid], k = 0;
+    int pat_greater;                                  /* text[p..) > text[s..) ? */
+    for (;;) {
+      if (s + k >= cmp_end) {                         /* the block suffix reached cmp_end: gt of position p + (cmp_end - s) w.r.t. cmp_end */
+        i64 q = p + (cmp_end - s);
+        pat_greater = q < n ? bit_get(gt_cmp_end, n - q) : 0;
+        break;
+      }
+      if (p + k >= n) { pat_greater = 0; break; }     /* pattern exhausted: it is a proper prefix, hence smaller */
+      if (text[s + k] != text[p + k]) { pat_greater = text[p + k] > text[s + k]; break; }
+      ++k;
+    }
+    if (pat_greater) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Whole run, restating partial_sufsort (partial_sufsort.hpp:558-584) and the */
 /* six steps of process_block (partial_sufsort.hpp:67-551) with the sorter    */
 /* replaced by "filter the full SA" (orc_partial_sa).  The result of the gap  */

@@ -7,8 +7,8 @@
 // the reference is NOT buildable here (libdivsufsort/libsais are absent and we
 // do not write stand-ins); the headers on the streaming-gap + merge path
 // (rank.hpp, compute_gap.hpp, gap_array.hpp, bwt_merge.hpp,
-// compute_{left,right}_gap.hpp, merge.hpp) do not need the sorter and compile
-// as they are.
+// compute_{left,right}_gap.hpp, merge.hpp, em_compute_initial_ranks.hpp with
+// approx_rank.hpp / sparse_isa.hpp) do not need the sorter and compile as they are.
 //
 // The reference works on files; each wrapper stages its inputs into `workdir`
 // and reads the reference's output files back.
@@ -35,6 +35,7 @@
 #include "compute_right_gap.hpp"
 #include "compute_left_gap.hpp"
 #include "merge.hpp"
+#include "em_compute_initial_ranks.hpp"
 
 using namespace psascan_private;
 
@@ -249,6 +250,65 @@ int ref_merge(int H, const long *beg, const long *size, const int *const *psa, c
               long ram_use, const char *workdir, uint8_t *out_sa5) {
   return g_uint40 ? merge_T<uint40>(H, beg, size, psa, gap, ram_use, workdir, out_sa5)
                   : merge_T<int>(H, beg, size, psa, gap, ram_use, workdir, out_sa5);
+}
+
+// em_compute_initial_ranks, first overload (em_compute_initial_ranks.hpp:222-319; call sites partial_sufsort.hpp:189,385):
+// ranks of the stream-chunk starts block_end + t * ceil(tail/threads) among the block's suffixes; a comparison that
+// reaches block_end is decided by gt bits w.r.t. block_end (gt bit u <-> position tail_end - u, u in [0, tail_end - block_end)),
+// ranges that stay open after max_lcp symbols by the sparse ISA (approx_rank.hpp, sparse_isa.hpp).
+long ref_initial_ranks(const uint8_t *text, long n, long block_beg, long block_end, const int *psa, const uint8_t *bwt, long i0,
+                       long tail_end, const uint8_t *gt, long rank_after_tail, long max_threads, const char *workdir, long *out) {
+  std::string wd(workdir), text_fn = wd + "/ref_text_ir.bin", gfn = wd + "/ref_gt_ir.bin";
+  utils::write_objects_to_file(text, n, text_fn);
+  long nbytes = (tail_end - block_end + 7) / 8;
+  std::vector<uint8_t> z(nbytes + 1, 0);
+  if (gt) memcpy(z.data(), gt, nbytes);
+  utils::write_objects_to_file(z.data(), nbytes, gfn);
+  multifile *mf = new multifile();
+  mf->add_file(n - tail_end, n - block_end, gfn);
+  std::vector<long> res;
+  silence(true);
+  if (g_uint40) {
+    std::vector<uint40> p40((size_t)(block_end - block_beg));
+    for (long k = 0; k < block_end - block_beg; ++k) p40[(size_t)k] = uint40((long)psa[k]);
+    em_compute_initial_ranks<uint40>(text + block_beg, p40.data(), bwt, i0, block_beg, block_end, n, text_fn, mf, res, max_threads, tail_end, rank_after_tail);
+  } else {
+    em_compute_initial_ranks<int>(text + block_beg, psa, bwt, i0, block_beg, block_end, n, text_fn, mf, res, max_threads, tail_end, rank_after_tail);
+  }
+  silence(false);
+  for (size_t t = 0; t < res.size(); ++t) out[t] = res[t];
+  delete mf;   // (the multifile deletes its files)
+  utils::file_delete(text_fn);
+  return (long)res.size();
+}
+
+// second overload (em_compute_initial_ranks.hpp:513-561; call site partial_sufsort.hpp:311): the block is followed by a
+// "mid block" [block_end, tail_begin) whose text is read, comparisons reaching tail_begin are decided by gt bits w.r.t.
+// tail_begin (gt bit u <-> position n - u).
+long ref_initial_ranks2(const uint8_t *text, long n, long block_beg, long block_end, const int *psa, long tail_begin,
+                        const uint8_t *gt, long max_threads, const char *workdir, long *out) {
+  std::string wd(workdir), text_fn = wd + "/ref_text_ir2.bin", gfn = wd + "/ref_gt_ir2.bin";
+  utils::write_objects_to_file(text, n, text_fn);
+  long nbytes = (n - tail_begin + 7) / 8;
+  std::vector<uint8_t> z(nbytes + 1, 0);
+  if (gt) memcpy(z.data(), gt, nbytes);
+  utils::write_objects_to_file(z.data(), nbytes, gfn);
+  multifile *mf = new multifile();
+  mf->add_file(0, n - tail_begin, gfn);
+  std::vector<long> res;
+  silence(true);
+  if (g_uint40) {
+    std::vector<uint40> p40((size_t)(block_end - block_beg));
+    for (long k = 0; k < block_end - block_beg; ++k) p40[(size_t)k] = uint40((long)psa[k]);
+    em_compute_initial_ranks<uint40>(text + block_beg, p40.data(), block_beg, block_end, n, text_fn, mf, res, max_threads, tail_begin);
+  } else {
+    em_compute_initial_ranks<int>(text + block_beg, psa, block_beg, block_end, n, text_fn, mf, res, max_threads, tail_begin);
+  }
+  silence(false);
+  for (size_t t = 0; t < res.size(); ++t) out[t] = res[t];
+  delete mf;
+  utils::file_delete(text_fn);
+  return (long)res.size();
 }
 
 }  // extern "C"

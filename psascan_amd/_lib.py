@@ -58,6 +58,12 @@ class HbSliceDescC(C.Structure):
                 ("psa_first", C.c_int64), ("psa_count", C.c_int64)]
 
 
+class LeafMergeStatsC(C.Structure):
+    _fields_ = [("levels", C.c_int64), ("passes", C.c_int64), ("suffixes", C.c_int64), ("prepare_ms", C.c_double), ("rank_ms", C.c_double),
+                ("search_ms", C.c_double), ("stream_ms", C.c_double), ("hist_ms", C.c_double), ("bitvector_ms", C.c_double), ("merge_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
 
 # every symbol include/psascan_amd.h declares: name -> (restype, argtypes)
@@ -115,6 +121,7 @@ SIGNATURES = {
     "psg_bits_rank1": (_int, [_vp, _i64, C.POINTER(_i64), _i64, C.POINTER(_i64)]),
     "psg_merge_plan_create_sliced": (_int, [C.POINTER(HbSliceDescC), _int, C.POINTER(_vp)]),
     "psg_merge_stream": (_int, [C.POINTER(HbHostDescC), _int, _i64, C.POINTER(MergeCheckC), SINK_FN, _vp, C.POINTER(MergeStreamStatsC)]),
+    "psg_merge_leaves": (_int, [C.POINTER(SearchCtxC), _i64, _i64, C.POINTER(_i64), _i64, _vp, _int, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(LeafMergeStatsC)]),
     "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
     "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "psg_last_kernel_ms": (C.c_double, []),

@@ -336,6 +336,20 @@ def halfblock_from_psa(sc, beg, size, d_psa, want_gt=True, d_psa_hi=None):
     return d_bwt, i0.value, d_gt
 
 
+def merge_leaves(sc, beg, size, leaf_bounds, d_leaf_psa, psa_bytes):
+    """psg_merge_leaves: the batched in-memory pSAscan merging (inmem_psascan.hpp:64-304).  leaf_bounds: absolute text
+    positions, leaf l = [leaf_bounds[l], leaf_bounds[l+1]); d_leaf_psa: the leaves' partial SAs back to back (positions
+    relative to the leaf, 2 or 4 bytes).  -> (d_psa u32 relative to beg, d_bwt, i0, d_gt_begin, stats)"""
+    from ._lib import LeafMergeStatsC
+    lb = np.ascontiguousarray(leaf_bounds, np.int64)
+    d_psa, d_bwt, d_gt = DeviceBuffer(4 * size + 16), DeviceBuffer(size + 16), zeros(4 * ((size + 31) // 32 + 2))
+    i0 = C.c_int64(-1)
+    st = LeafMergeStatsC()
+    check(lib().psg_merge_leaves(C.byref(sc), beg, size, lb.ctypes.data_as(C.POINTER(C.c_int64)), len(lb) - 1, _ptr(d_leaf_psa), psa_bytes,
+                                 d_psa.ptr, d_bwt.ptr, C.byref(i0), d_gt.ptr, C.byref(st)))
+    return d_psa, d_bwt, i0.value, d_gt, st
+
+
 def bits_rank1(d_bits, nbits, positions):
     """ones in d_bits[0 .. pos) for every pos (rank1 of ranksel_support.hpp:45-187)"""
     pos = np.ascontiguousarray(positions, np.int64)

@@ -732,6 +732,75 @@ __global__ __launch_bounds__(PSG_WG) void merge2_kernel(MergeLevel L0, MergeLeve
   for (int bb = 4 * ndw + threadIdx.x; bb < nbytes; bb += PSG_WG) obase[bb] = ((const u8 *)packed)[bb];   // ragged end of the last tile
 }
 
+// Many two-way merges in one launch: the pairs (block, tail) of one level of the leaf merging (leaf_tree.hip).  bv is
+// the concatenation of the pairs' merge bitvectors -- bit x belongs to the pass whose parent range holds position x --
+// and the arrays are indexed by position: the block of pass p at [lbeg, lbeg + m), its tail behind it.  Partial SA
+// values (relative to the enclosing range, u32) and BWT symbols move together (merge.hpp:123-158 for two half-blocks +
+// bwt_merge.hpp:66-140 in one sweep).
+__global__ __launch_bounds__(PSG_WG) void merge_pairs_kernel(const u32 *bv, i64 nbits, const u64 *samp, const psg::BatchGeom *geom, i64 npass, const u32 *tile_pass,
+                                                               const u32 *psa, const u8 *bwt, const u8 *text, u32 *psa_out, u8 *bwt_out, i64 *i0_out) {
+  __shared__ u32 scratch[8];
+  const i64 x0 = (i64)blockIdx.x * MT;
+  const int len = (int)std::min<i64>(MT, nbits - x0);
+  const int e0 = threadIdx.x * MEPT;
+  MergeLevel L0{};
+  L0.mbv = bv; L0.nbits = nbits; L0.samp = samp;
+  u32 bits, part;
+  i64 sm;
+  merge_level_loads(L0, x0, len, bits, part, sm);
+  const u32 part_tot = block_sum<u32>(part, scratch);
+  const i64 ones_x0 = sm + part_tot;
+  const int n = std::max(0, std::min(MEPT, len - e0));
+  u32 tot1;
+  const u32 o = block_excl_scan<u32>((u32)__popc(bits), scratch, tot1);
+  if (n <= 0) return;
+  i64 p = tile_pass[blockIdx.x];
+  psg::BatchGeom G = geom[p];
+  u32 v[MEPT], c[MEPT];
+#pragma unroll
+  for (int q = 0; q < MEPT; ++q) {
+    v[q] = 0; c[q] = 0;
+    if (q < n) {
+      const i64 x = x0 + e0 + q;
+      while (x >= G.lbeg + G.m + G.T && p + 1 < npass) { ++p; G = geom[p]; }
+      const bool one = (bits >> q) & 1u;
+      const i64 r1 = ones_x0 + o + __popc(bits & ((1u << q) - 1u)) - G.ones_before;   // tail elements of this pass in front of x
+      const i64 src = one ? G.lbeg + G.m + r1 : x - r1;
+      v[q] = gload(psa + src);
+      c[q] = gload(bwt + src);
+      if (one && v[q] == (u32)(G.lbeg + G.m)) c[q] = text[G.lbeg + G.m - 1];          // the tail's first suffix: dummy -> the block's last symbol
+      if (!one && v[q] == (u32)G.lbeg) i0_out[p] = x - G.lbeg;                        // the block's first suffix is the parent's
+    }
+  }
+  u32 *po = psa_out + x0 + e0;
+  u8 *bo = bwt_out + x0 + e0;
+  if (n == MEPT) {
+    ((uint4 *)po)[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    ((uint4 *)po)[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    *(uint2 *)bo = make_uint2(c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24), c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24));
+  } else {
+    for (int q = 0; q < n; ++q) { po[q] = v[q]; bo[q] = (u8)c[q]; }
+  }
+}
+
+int psg::merge_pairs_tile() { return MT; }
+
+int psg::merge_pairs_launch(const u32 *d_bv, i64 nbits, const BatchGeom *d_geom, i64 npass, const u32 *d_tile_pass, const u32 *d_psa, const u8 *d_bwt,
+                            const u8 *d_text_range, u32 *d_psa_out, u8 *d_bwt_out, i64 *d_i0_out) {
+  static_assert(MEPT == 8, "merge_pairs_kernel stores 8 entries per thread");
+  PSG_REQUIRE(d_bv && nbits >= 1 && d_geom && npass >= 1 && d_tile_pass && d_psa && d_bwt && d_psa_out && d_bwt_out && d_i0_out, "merge_pairs_launch");
+  PSG_REQUIRE(((uintptr_t)d_psa_out & 15) == 0 && ((uintptr_t)d_bwt_out & 7) == 0, "merge_pairs_launch: output alignment");
+  const i64 ntiles = cdiv(nbits, TILE_B);
+  DevBuf samp;
+  if (int rc = samp.alloc((ntiles + 1) * 8)) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_bv, nbits, samp.as<u64>());
+  if (int rc = scan_u64_inplace(samp.as<u64>(), ntiles, nullptr)) return rc;
+  hipLaunchKernelGGL(merge_pairs_kernel, dim3((unsigned)cdiv(nbits, MT)), dim3(PSG_WG), 0, stream(), d_bv, nbits, samp.as<u64>(), d_geom, npass, d_tile_pass, d_psa, d_bwt,
+                     d_text_range, d_psa_out, d_bwt_out, d_i0_out);
+  PSG_HIP(hipGetLastError());
+  return 0;   // (samp goes back to the pool: reuse is stream-ordered)
+}
+
 extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
   if (!p) return;
   for (void *q : p->owned) psg::pool_free(q);

@@ -146,6 +146,35 @@ int check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i6
 int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank);
 int search_window_check();   // after the search has completed: PSG_EWINDOW if a comparison left the context's text window
 
+// ---- batched passes: many (block, tail) pairs of one level of the leaf merging in one launch (rank_stream.hip,
+// bits_merge.hip, leaf_tree.hip).  Positions are relative to the begin of the enclosing range; the blocks' BWTs lie
+// at their positions in ONE array over which ONE rank structure is built.
+struct BatchGeom {
+  i64 lbeg, m, T;            // block = [lbeg, lbeg + m), tail = the m.. T positions behind it
+  i64 kbase;                 // first chain of this pass among all chains of the launch
+  i64 gap_base;              // first slot of the pass in the shared gap array (slot m of a pass = slot 0 of the next)
+  i64 ones_before;           // sum of T over the passes in front = one bits in front of lbeg in the merge bitvector
+  i64 gt_in_word, gt_l_word; // word offsets of the tail's / the block's gt array in the level's current gt buffer
+  i64 gt_out_word;           // word offset of the parent's gt array in the next level's buffer
+  i64 node;                  // index of the block's node (i0 array)
+};
+struct BatchTables;          // per-launch tables of the rank structure (owned by the caller of stream_batch_setup)
+BatchTables *stream_batch_tables_create(const psg_rank_t *r, i64 npass);
+void stream_batch_tables_free(BatchTables *t);
+// fills the pass table of a launch on the device: per-pass C arrays folded with the structure's counts in front of the
+// block (LDS tables), the pass parameters.  Enqueue only.
+int stream_batch_setup(const psg_rank_t *r, BatchTables *tabs, const BatchGeom *d_geom, i64 npass, const i64 *d_i0_nodes, const u8 *d_text_range,
+                       const u32 *d_gt_cur, u32 *d_gt_new, i64 L, i64 *d_init, i64 *d_fin, u32 *d_log, i64 Ktotal, u32 *d_gap, GapExcess ex);
+// mode 0 / 1 / 2: atomics, atomics with carries, rank log (32-bit).  Enqueue only.
+int stream_batch_launch(const psg_rank_t *r, const BatchTables *tabs, const u32 *d_wg_pass, const u32 *d_wg_local, i64 nwg, int mode);
+int stream_batch_blocks_per_cu(const psg_rank_t *r, int mode);
+// out[x] = bit x of bv ? tail element : block element, for every pass of the level (positions [0, nbits)): partial SA
+// values and BWT symbols move together; the tail's dummy symbol is patched with the block's last symbol
+// (bwt_merge.hpp:128), i0_out[pass] = where the block's first suffix lands (bwt_merge.hpp:133).  Enqueue only.
+int merge_pairs_launch(const u32 *d_bv, i64 nbits, const BatchGeom *d_geom, i64 npass, const u32 *d_tile_pass, const u32 *d_psa, const u8 *d_bwt,
+                       const u8 *d_text_range, u32 *d_psa_out, u8 *d_bwt_out, i64 *d_i0_out);
+int merge_pairs_tile();      // output slots per tile (d_tile_pass[t] = pass that holds slot t * tile)
+
 // single-workgroup exclusive scan of n u64 values in place; total -> d_total (may be null)
 int scan_u64_inplace(u64 *d_vals, i64 n, u64 *d_total);
 

@@ -412,6 +412,11 @@ struct StreamParams {
   i64 K;              // total number of chains (log row length)
   u32 *log_hi;        // MODE 3: bits 32..39 of the ranks, one byte per entry at the same index (0xFF + low word PAD = no entry)
   psg::GapExcess ex;  // MODE 1: where wrapping counters leave their carries
+  // batched passes (stream_batch_kernel: many small passes over ONE rank structure built on the concatenation of their
+  // blocks): the block of this pass starts at position rank_off of the structure, its gap slots at gap_base of the
+  // shared gap array; 0 / 0 for an ordinary pass
+  i64 rank_off;
+  i64 gap_base;
 };
 
 // MODE 0: atomicAdd on the gap counters (a fresh array of 32-bit counters and a tail below 2^32: nothing can wrap);
@@ -460,19 +465,12 @@ __device__ __forceinline__ TextBlock load_text_block(const uint4 *bp, int first)
     (c).thi = (u64)tb_.cur.z | ((u64)tb_.cur.w << 32);           \
   } while (0)
 
-template <int CNT, int B, int MODE, int CPL>
-// MODE 3 needs 82 VGPRs as the compiler allocates freely = 5 waves per SIMD (MODE 2: 76 = 6 waves); the kernel hides its
-// memory latency with resident chains, and 5 instead of 6 workgroups per CU cost 12 % per suffix at configs[2]: ask
-// for 6 (<= 80 VGPRs) there
-__global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WAVES < 6 ? 6 : (B <= 64 ? PSG_STREAM_MIN_WAVES : 1))) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
-  extern __shared__ u64 lds[];
-  __shared__ u32 lstage[MODE >= 2 ? CPL * 4 * PSG_WG : 1];
-  __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
+// The body of the stream kernel: lane `gid` of the pass runs its CPL chains.  BATCH: the pass is one of many over a
+// shared rank structure (P.rank_off, P.gap_base); T1 then holds C[c] - rank(rank_off, c) modulo 2^56.
+template <int CNT, int B, int MODE, int CPL, bool BATCH>
+__device__ __forceinline__ void stream_body(const RankView<CNT, B> &R, const StreamParams &P, const u64 *T1, const u64 *tot, u32 *lstage, u32 *gstage, i64 gid) {
   const bool gt16 = P.gt_out && ((uintptr_t)P.gt_out & 15) == 0 && (P.L & 127) == 0;
-  load_tables(lds, P.g_T1, P.g_tot, P.nsb);
-  const u64 *T1 = lds, *tot = lds + P.nsb * 256;
   const i64 nlanes = (P.nchains + CPL - 1) / CPL;
-  i64 gid = (i64)blockIdx.x * PSG_WG + threadIdx.x;
   if (gid >= nlanes) return;
   Chain S[CPL];
 #pragma unroll
@@ -527,7 +525,7 @@ __global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WA
           c.tlo <<= 8;
           gti0[q] = c.i > P.i0;
           c.gout |= (u32)gti0[q] << t;
-          rank_issue<CNT, B>(R, T1, tot, c.i, sym[q], req[q]);
+          rank_issue<CNT, B>(R, T1, tot, BATCH ? c.i + P.rank_off : c.i, sym[q], req[q]);
         }
       }
 #pragma unroll
@@ -535,6 +533,7 @@ __global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WA
         if (t < steps[q]) {
           Chain &c = S[q];
           i64 ni = rank_finish<CNT, B>(R, sym[q], req[q]);
+          if (BATCH) ni &= (i64)VAL_MASK;
           ni -= (gti0[q] && sym[q] == 0) ? 1 : 0;
           ni += (sym[q] == P.last && ((c.gin >> t) & 1u)) ? 1 : 0;
           c.i = ni;
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WA
             // 4 consecutive ranks of a chain leave as ONE dwordx4 store (memory instructions per step
             // are the scarce resource of this kernel); lane-private LDS slots, no barrier needed
             u32 *ls = lstage + q * 4 * PSG_WG;
-            ls[(t & 3) * PSG_WG + threadIdx.x] = (u32)ni;
+            ls[(t & 3) * PSG_WG + threadIdx.x] = (u32)(BATCH ? ni + P.gap_base : ni);
             if (MODE == 3) c.hiacc |= (u32)((u64)ni >> 32) << (8 * (t & 3));
             if ((t & 3) == 3) {
               uint4 q4 = make_uint4(ls[threadIdx.x], ls[PSG_WG + threadIdx.x], ls[2 * PSG_WG + threadIdx.x], ls[3 * PSG_WG + threadIdx.x]);
@@ -550,9 +549,9 @@ __global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WA
               if (MODE == 3) { P.log_hi[((g + t) >> 2) * P.K + c.k] = c.hiacc; c.hiacc = 0; }
             }
           } else if (MODE == 1) {
-            excess_add_atomic(P.ex, &P.gap[ni], (u64)ni, 1u);
+            excess_add_atomic(P.ex, &P.gap[BATCH ? ni + P.gap_base : ni], (u64)(BATCH ? ni + P.gap_base : ni), 1u);
           } else {
-            atomicAdd(&P.gap[ni], 1u);
+            atomicAdd(&P.gap[BATCH ? ni + P.gap_base : ni], 1u);
           }
           if (--c.tcnt == 0) {
             c.tcnt = 16;
@@ -614,6 +613,33 @@ __global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WA
       }
     P.fin[c.k] = c.i;
   }
+}
+
+template <int CNT, int B, int MODE, int CPL>
+// MODE 3 needs 82 VGPRs as the compiler allocates freely = 5 waves per SIMD (MODE 2: 76 = 6 waves); the kernel hides its
+// memory latency with resident chains, and 5 instead of 6 workgroups per CU cost 12 % per suffix at configs[2]: ask
+// for 6 (<= 80 VGPRs) there
+__global__ __launch_bounds__(PSG_WG, (CNT == 0 && MODE == 3 && PSG_STREAM_MIN_WAVES < 6 ? 6 : (B <= 64 ? PSG_STREAM_MIN_WAVES : 1))) void stream_kernel(RankView<CNT, B> R, StreamParams P) {
+  extern __shared__ u64 lds[];
+  __shared__ u32 lstage[MODE >= 2 ? CPL * 4 * PSG_WG : 1];
+  __shared__ u32 gstage[CPL * 4 * PSG_WG];   // 4 gt_out words (128 steps) of a chain leave as one 16-byte store
+  load_tables(lds, P.g_T1, P.g_tot, P.nsb);
+  stream_body<CNT, B, MODE, CPL, false>(R, P, lds, lds + P.nsb * 256, lstage, gstage, (i64)blockIdx.x * PSG_WG + threadIdx.x);
+}
+
+// Many small passes in ONE launch (the merging of host-sorted leaves, inmem_psascan.hpp:64-304: every pair of
+// neighbouring sub-ranges of a level is one pass): workgroup w serves pass wg_pass[w] -- its parameters come from a
+// table in device memory -- with the lanes wg_local[w] * 256 .. of that pass.  All passes share ONE rank structure,
+// built over the concatenation of their blocks' BWTs.
+template <int CNT, int B, int MODE>
+__global__ __launch_bounds__(PSG_WG, (B <= 64 ? PSG_STREAM_MIN_WAVES : 1)) void stream_batch_kernel(RankView<CNT, B> R, const StreamParams *passes, const u32 *wg_pass, const u32 *wg_local) {
+  extern __shared__ u64 lds[];
+  __shared__ u32 lstage[MODE >= 2 ? 4 * PSG_WG : 1];
+  __shared__ u32 gstage[4 * PSG_WG];
+  const u32 w = __builtin_amdgcn_readfirstlane(wg_pass[blockIdx.x]);
+  const StreamParams P = passes[w];
+  load_tables(lds, P.g_T1, P.g_tot, P.nsb);
+  stream_body<CNT, B, MODE, 1, true>(R, P, lds, lds + P.nsb * 256, lstage, gstage, (i64)__builtin_amdgcn_readfirstlane(wg_local[blockIdx.x]) * PSG_WG + threadIdx.x);
 }
 
 // Warm-up: find the start rank of chain k by running the recurrence on an interval
@@ -952,6 +978,106 @@ template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamPar
 #undef PSG_LAUNCH
 }
 
+// ---------------------------------------------------------------------------------------
+// batched passes (leaf_tree.hip): pass table + per-pass LDS tables, built on the device
+// ---------------------------------------------------------------------------------------
+struct psg::BatchTables {
+  DevBuf T1g, tot;            // the structure's own tables (C = 0)
+  DevBuf T1p;                 // [npass][nsb][256]
+  DevBuf passes;              // [npass] StreamParams
+  i64 npass = 0;
+};
+psg::BatchTables *psg::stream_batch_tables_create(const psg_rank_t *r, i64 npass) {
+  BatchTables *t = new BatchTables();
+  t->npass = npass;
+  if (make_tables(r, nullptr, t->T1g, t->tot) || t->T1p.alloc(npass * (i64)r->nsb * 256 * 8) || t->passes.alloc(npass * (i64)sizeof(StreamParams))) { delete t; return nullptr; }
+  return t;
+}
+void psg::stream_batch_tables_free(BatchTables *t) { delete t; }
+
+// workgroup p, thread c: counts of symbol c in front of / inside the block of pass p, the pass's C array
+// (compute_gap.hpp:77-85), T1p[p][sb][c] = C[c] - rank(lbeg, c) + base of superblock sb (mod 2^56); thread 0 writes
+// the pass parameters.
+template <int CNT, int B>
+__global__ __launch_bounds__(256) void batch_setup_kernel(RankView<CNT, B> R, const u64 *g_T1, const u64 *g_tot, int nsb, const psg::BatchGeom *geom,
+                                                           const i64 *i0_nodes, const u8 *text, const u32 *gt_cur, u32 *gt_new, i64 L, i64 *init, i64 *fin,
+                                                           u32 *log, i64 Ktotal, u32 *gap, psg::GapExcess ex, u64 *T1p, StreamParams *passes) {
+  extern __shared__ u64 lds[];
+  __shared__ i64 scratch[8];
+  load_tables(lds, g_T1, g_tot, nsb);
+  const u64 *T1 = lds, *tot = lds + nsb * 256;
+  const psg::BatchGeom G = geom[blockIdx.x];
+  const u32 c = threadIdx.x;
+  const u32 last = text[G.lbeg + G.m - 1];
+  const i64 before = lf_core<CNT, B>(R, T1, tot, G.lbeg, c), upto = lf_core<CNT, B>(R, T1, tot, G.lbeg + G.m, c);
+  i64 total;
+  const i64 v = (upto - before) + (c == last ? 1 : 0) - (c == 0 ? 1 : 0);
+  const i64 C = block_excl_scan<i64>(v, scratch, total);
+  u64 *out = T1p + (i64)blockIdx.x * nsb * 256;
+  for (int sb = 0; sb < nsb; ++sb) {
+    const u64 g = T1[sb * 256 + c];
+    out[sb * 256 + c] = (((g & VAL_MASK) + (u64)(C - before)) & VAL_MASK) | (g & ~VAL_MASK);
+  }
+  if (c == 0) {
+    StreamParams P{};
+    P.tail = text + G.lbeg + G.m; P.T = G.T; P.ctx = 0;
+    P.gt_in = gt_cur + G.gt_in_word; P.gt_out = gt_new + G.gt_out_word; P.gap = gap;
+    P.i0 = i0_nodes[G.node]; P.last = last; P.L = L; P.nchains = (G.T + L - 1) / L; P.list = nullptr;
+    P.init = init + G.kbase; P.fin = fin + G.kbase; P.g_T1 = out; P.g_tot = g_tot; P.nsb = nsb; P.ovf_flag = nullptr;
+    P.log = log ? log + 4 * G.kbase : nullptr; P.K = Ktotal; P.log_hi = nullptr; P.ex = ex;
+    P.rank_off = G.lbeg; P.gap_base = G.gap_base;
+    passes[blockIdx.x] = P;
+  }
+}
+template <int CNT, int B>
+static void launch_batch_setup(const psg_rank *r, psg::BatchTables *t, const psg::BatchGeom *geom, i64 npass, const i64 *i0_nodes, const u8 *text, const u32 *gt_cur,
+                               u32 *gt_new, i64 L, i64 *init, i64 *fin, u32 *log, i64 Ktotal, u32 *gap, psg::GapExcess ex) {
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
+  hipLaunchKernelGGL((batch_setup_kernel<CNT, B>), dim3((unsigned)npass), dim3(256), lds, stream(), R, t->T1g.as<u64>(), t->tot.as<u64>(), r->nsb, geom, i0_nodes, text,
+                     gt_cur, gt_new, L, init, fin, log, Ktotal, gap, ex, t->T1p.as<u64>(), t->passes.as<StreamParams>());
+}
+int psg::stream_batch_setup(const psg_rank_t *r, BatchTables *t, const BatchGeom *d_geom, i64 npass, const i64 *d_i0_nodes, const u8 *d_text_range, const u32 *d_gt_cur,
+                            u32 *d_gt_new, i64 L, i64 *d_init, i64 *d_fin, u32 *d_log, i64 Ktotal, u32 *d_gap, GapExcess ex) {
+  PSG_REQUIRE(r && t && t->npass == npass && npass >= 1 && L >= 4 && (L & 3) == 0, "stream_batch_setup");
+  DISPATCH_LAYOUT(r, launch_batch_setup, r, t, d_geom, npass, d_i0_nodes, d_text_range, d_gt_cur, d_gt_new, L, d_init, d_fin, d_log, Ktotal, d_gap, ex);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+template <int CNT, int B>
+static void launch_stream_batch(const psg_rank *r, const psg::BatchTables *t, const u32 *wg_pass, const u32 *wg_local, i64 nwg, int mode) {
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
+  const dim3 grid((unsigned)nwg);
+  const StreamParams *passes = t->passes.as<StreamParams>();
+  if (mode == 2) hipLaunchKernelGGL((stream_batch_kernel<CNT, B, 2>), grid, dim3(PSG_WG), lds, stream(), R, passes, wg_pass, wg_local);
+  else if (mode == 1) hipLaunchKernelGGL((stream_batch_kernel<CNT, B, 1>), grid, dim3(PSG_WG), lds, stream(), R, passes, wg_pass, wg_local);
+  else hipLaunchKernelGGL((stream_batch_kernel<CNT, B, 0>), grid, dim3(PSG_WG), lds, stream(), R, passes, wg_pass, wg_local);
+}
+int psg::stream_batch_launch(const psg_rank_t *r, const BatchTables *t, const u32 *d_wg_pass, const u32 *d_wg_local, i64 nwg, int mode) {
+  PSG_REQUIRE(r && t && nwg >= 1 && mode >= 0 && mode <= 2, "stream_batch_launch");
+  DISPATCH_LAYOUT(r, launch_stream_batch, r, t, d_wg_pass, d_wg_local, nwg, mode);
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+template <int CNT, int B> static void batch_occupancy(const psg_rank *r, int mode, int *blocks) {
+  const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
+  *blocks = 0;
+  if (mode == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_batch_kernel<CNT, B, 2>, PSG_WG, 0);
+  else if (mode == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_batch_kernel<CNT, B, 1>, PSG_WG, 0);
+  else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, stream_batch_kernel<CNT, B, 0>, PSG_WG, 0);
+  (void)hipGetLastError();
+  const int by_lds = (int)(((size_t)160 << 10) / (lds + 8192 + 256));
+  if (*blocks > by_lds) *blocks = by_lds;
+  if (*blocks < 1) *blocks = 4;
+  if (*blocks > 8) *blocks = 8;
+}
+int psg::stream_batch_blocks_per_cu(const psg_rank_t *r, int mode) {
+  int blocks = 4;
+  if (r->cnt == 0) batch_occupancy<0, 0>(r, mode, &blocks);
+  return blocks;
+}
+
 // resident workgroups per CU of the stream kernel that will be launched (occupancy API)
 template <int CNT, int B> static void query_occupancy(const psg_rank *r, int mode, int cpl, int *blocks) {
   // The occupancy API budgets 64 KiB of LDS per CU; gfx950 has 160 KiB, and a block with three superblocks (a 4 GiB
@@ -1278,7 +1404,7 @@ static int stream_chunk(const PassArgs &A, int64_t *h_final_rank, psg_stream_sta
     if ((rc = log_d.alloc(K * L * 4))) return rc;   // every entry is written by its chain (0xFFFFFFFF = no entry)
     if (mode == 3 && (rc = loghi_d.alloc(K * L))) return rc;
   }
-  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K, loghi_d.as<u32>(), gex};
+  StreamParams SP{d_tail, T + ctx, ctx, d_gt_in, d_gt_out, d_gap, i0, (u32)last_sym, L, K, nullptr, lo_d.as<i64>(), fin_d.as<i64>(), T1.as<u64>(), tot.as<u64>(), r->nsb, flag_d.as<int>(), log_d.as<u32>(), K, loghi_d.as<u32>(), gex, 0, 0};
   double kms = 0;
   i64 ndone = 0;
   // rounds: every chain whose start rank is known runs; an unresolved chain k becomes

@@ -52,6 +52,8 @@ _lib.orc_vbyte_decode.restype = C.c_int64
 _lib.orc_merge.argtypes = [C.c_int, i64p, i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u8p]
 _lib.orc_psascan.argtypes = [u8p, C.c_int64, C.c_int64, C.c_int64, u8p]
 _lib.orc_psascan.restype = C.c_int
+_lib.orc_initial_rank.argtypes = [u8p, C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int64, C.c_void_p, C.c_int64]
+_lib.orc_initial_rank.restype = C.c_int64
 
 
 def as_u8(x):
@@ -169,6 +171,15 @@ def merge(begs, sizes, psas, gaps):
     return out
 
 
+def initial_rank(text, bb, be, psa, cmp_end, gt_cmp_end, p):
+    """#suffixes of [bb,be) smaller than text[p..): binary search over the partial SA, comparisons that reach cmp_end are
+    decided by gt_cmp_end (bit u <-> position n - u, w.r.t. cmp_end); em_compute_initial_ranks.hpp:54-76, 321-363."""
+    text = as_u8(text)
+    g = None if gt_cmp_end is None else as_u8(gt_cmp_end)
+    return _lib.orc_initial_rank(text, len(text), bb, be, np.ascontiguousarray(psa, np.int64), cmp_end,
+                                 None if g is None else g.ctypes.data, p)
+
+
 def psascan(text, max_block_size, ram_use=None):
     text = as_u8(text)
     out = np.zeros(5 * len(text), np.uint8)
@@ -222,6 +233,12 @@ def ref_lib():
     L.ref_gap_save_vbyte.argtypes = [u64p, C.c_long, C.c_char_p, u8p]
     L.ref_gap_save_vbyte.restype = C.c_long
     L.ref_merge.argtypes = [C.c_int, i64p, i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_long, C.c_char_p, u8p]
+    if hasattr(L, "ref_initial_ranks"):
+        L.ref_initial_ranks.argtypes = [u8p, C.c_long, C.c_long, C.c_long, i32p, u8p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
+                                        C.c_char_p, i64p]
+        L.ref_initial_ranks.restype = C.c_long
+        L.ref_initial_ranks2.argtypes = [u8p, C.c_long, C.c_long, C.c_long, i32p, C.c_long, C.c_void_p, C.c_long, C.c_char_p, i64p]
+        L.ref_initial_ranks2.restype = C.c_long
     return L
 
 

@@ -469,7 +469,12 @@ def test_initial_ranks_vs_definition(A, kind):
     # pass A shape: the left half only, comparisons still run to e; positions from mid on
     posA = np.concatenate([[mid, mid + 1, e], rng.integers(mid, n + 1, 300)]).astype(np.int64)
     scA = A.search_ctx(d_text, n, e, gt, [(b, mid - b, dL, None)])
-    assert np.array_equal(A.initial_ranks(scA, posA), [rank_of(p, b, mid) for p in posA])
+    gotA = A.initial_ranks(scA, posA)
+    assert np.array_equal(gotA, [rank_of(p, b, mid) for p in posA])
+    # ... and equal to the oracle's search, which tests/test_oracle.py::test_ref_initial_ranks pins to the reference's own
+    # em_compute_initial_ranks (both overloads); here with the comparison boundary of this context (e, gt w.r.t. e)
+    gt_n = orc.packbits([0] + [int((isa[n - u] if u > 0 else -1) > isa[e]) for u in range(1, n - e)] + [0] * 64)
+    assert np.array_equal(gotA, [orc.initial_rank(t, b, mid, psaL, e, gt_n, int(p)) for p in posA])
     # last block: comparisons run to the end of the text, no gt bits
     psaZ, _, _, _ = orc.partial_sa(t, sa, isa, e, n - 100)
     scZ = A.search_ctx(d_text, n, n, None, [(e, n - 100 - e, A.upload(psaZ.astype(np.uint32)), None)])
@@ -1034,3 +1039,96 @@ def test_pipeline_small_shapes(A, n, mb):
     for ram in (int(mb * 5.2) + 1, 30, 10 * 1000000):
         out = pipeline.construct_sa5(t, mb, ram, oracle_sorter(sa, orc.inverse(sa)), max_chains=16)
         assert np.array_equal(orc.sa5_to_sa(out), sa)
+
+
+# ------------------------------------------------------------------ batched leaf merging (in-memory pSAscan, inmem_psascan.hpp:64-304)
+def _leaf_case(A, t, b, e, bounds, psa_bytes):
+    """leaves of [b, e) cut at `bounds` (absolute), each one's partial SA from the oracle -> psg_merge_leaves"""
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    dt = np.uint16 if psa_bytes == 2 else np.uint32
+    parts = []
+    for lb, le in zip(bounds[:-1], bounds[1:]):
+        psa, _, _, _ = orc.partial_sa(t, sa, isa, int(lb), int(le), want_gt=False)
+        parts.append(psa.astype(dt))
+    d_text = A.upload(t, pad_to=64)
+    sc = A.search_ctx(d_text, n, n, None, [])
+    d_psa, d_bwt, i0, d_gt, st = A.merge_leaves(sc, b, e - b, bounds, A.upload(np.concatenate(parts)), psa_bytes)
+    want_psa, want_bwt, want_i0, want_gt = orc.partial_sa(t, sa, isa, b, e)
+    assert i0 == want_i0
+    assert np.array_equal(A.download(d_psa, np.uint32, e - b).astype(np.int64), want_psa)
+    assert np.array_equal(A.download(d_bwt, np.uint8, e - b), want_bwt)
+    assert np.array_equal(orc.bits(A.download(d_gt, np.uint8, (e - b + 7) // 8), e - b), orc.bits(want_gt, e - b))
+    return st
+
+
+@pytest.mark.parametrize("kind", ["rand255", "sig4z", "dna", "sig12", "zeros_mix", "alla", "per3", "fib", "zeros"])
+@pytest.mark.parametrize("nleaves,psa_bytes", [(1, 4), (2, 2), (3, 4), (8, 2), (13, 4), (64, 2)])
+def test_merge_leaves_vs_oracle(A, kind, nleaves, psa_bytes):
+    """psg_merge_leaves == the oracle's partial SA / BWT / i0 / gt bits of the range, for even and odd leaf counts (a node
+    without a partner is carried up a level), leaves of unequal sizes, ranges in the middle and at the end of the text."""
+    n = 30_011
+    rng = np.random.default_rng(nleaves * 3 + psa_bytes)
+    t = np.where(rng.random(n) < 0.3, 0, rng.integers(1, 6, n)).astype(np.uint8) if kind == "zeros_mix" else make_text(kind, n, 5)
+    for b, e in ((1_003, 21_777), (9_000, n)):
+        cuts = np.sort(rng.choice(np.arange(b + 1, e), nleaves - 1, replace=False)) if nleaves > 1 else np.array([], np.int64)
+        bounds = np.concatenate([[b], cuts, [e]]).astype(np.int64)
+        st = _leaf_case(A, t, b, e, bounds, psa_bytes)
+        assert st.passes == nleaves - 1 and st.suffixes > 0 or nleaves == 1
+
+
+@pytest.mark.parametrize("mode", ["atomic", "log", "ovf"])
+def test_merge_leaves_gap_modes_and_chain_lengths(A, monkeypatch, mode):
+    """the three gap-update modes of the batched stream kernel and short / long chains give the same result"""
+    monkeypatch.setenv("PSG_GAP_MODE", mode)
+    if mode == "ovf":
+        monkeypatch.setenv("PSG_GAP_COUNTER_BITS", "8")
+    t = make_text("sig4z", 200_003, 9)
+    t[50_000:50_400] = 1                                   # a run: gap values beyond 8 bits somewhere
+    for L in ("32", "128", "1024"):
+        monkeypatch.setenv("PSG_BATCH_CHAIN_LEN", L)
+        b, e = 10_000, 190_000
+        bounds = np.linspace(b, e, 24).astype(np.int64)
+        _leaf_case(A, t, b, e, bounds, 2)
+
+
+def test_merge_leaves_many_superblocks_and_block_layouts(A, monkeypatch):
+    """the level-wide rank structure with several superblocks (PSG_SM_SB_SHIFT) and the interleaved-block fallback layouts"""
+    t = make_text("sig12", 150_001, 3)
+    b, e = 5_000, 150_001
+    bounds = np.linspace(b, e, 18).astype(np.int64)
+    monkeypatch.setenv("PSG_SM_SB_SHIFT", "12")
+    _leaf_case(A, t, b, e, bounds, 4)
+    monkeypatch.delenv("PSG_SM_SB_SHIFT")
+    monkeypatch.setenv("PSG_RANK_LAYOUT", "block")
+    _leaf_case(A, t, b, e, bounds, 4)
+    monkeypatch.setenv("PSG_BLOCK_SB_SHIFT", "14")
+    _leaf_case(A, make_text("rand255", 150_001, 3), b, e, bounds, 4)
+
+
+def test_merge_leaves_through_a_text_window(A):
+    """a text that stays in host memory: the device sees the range and a look-ahead behind it; a comparison between leaves
+    that would leave the window fails the call (PSG_EWINDOW) instead of reading outside"""
+    from psascan_amd._lib import PsgError
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 250, 3_000, dtype=np.uint8)
+    t = np.concatenate([rng.integers(0, 250, 2_000, dtype=np.uint8), x, rng.integers(0, 250, 1_000, dtype=np.uint8), x, rng.integers(0, 250, 9_000, dtype=np.uint8)])
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = 1_000, 8_500                                     # the second copy of x (6000..9000) runs 500 symbols past the range
+    bounds = np.array([b, 3_100, 5_000, 6_700, e], np.int64)
+    parts = [orc.partial_sa(t, sa, isa, int(lo), int(hi), want_gt=False)[0].astype(np.uint16) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    d_leaf = A.upload(np.concatenate(parts))
+    want_psa, want_bwt, want_i0, _ = orc.partial_sa(t, sa, isa, b, e)
+    for w_end, ok in ((n, True), (e + 1_000, True), (e + 100, False)):
+        win = A.upload(t[b:w_end], pad_to=64)
+        sc = A.search_ctx(win, n, n, None, [], window=(b, w_end))
+        if ok:
+            d_psa, d_bwt, i0, _, _ = A.merge_leaves(sc, b, e - b, bounds, d_leaf, 2)
+            assert i0 == want_i0 and np.array_equal(A.download(d_psa, np.uint32, e - b).astype(np.int64), want_psa)
+        else:
+            with pytest.raises(PsgError) as ei:
+                A.merge_leaves(sc, b, e - b, bounds, d_leaf, 2)
+            assert ei.value.code == -7

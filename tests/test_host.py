@@ -490,8 +490,8 @@ def test_cli_edge_inputs(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["rand", "per3"])
-def test_cli_checkpoint_resume(tmp_path, kind):
+@pytest.mark.parametrize("kind,spill", [("rand", False), ("per3", False), ("rand", True)])
+def test_cli_checkpoint_resume(tmp_path, kind, spill):
     """--checkpoint DIR (the reference has no restart): the run is stopped after 2 and then after 3 more
     of its 7 blocks (--stop-after, exit status 3, as a crash would leave it), started again twice, and the .sa5 is the
     same bytes as an uninterrupted run's.  A checkpoint of another run is refused; a completed run leaves nothing behind."""
@@ -507,7 +507,8 @@ def test_cli_checkpoint_resume(tmp_path, kind):
     assert r.returncode == 0, r.stderr[-2000:]
     ck = tmp_path / "ck"
     out = tmp_path / "x.sa5"
-    cmd = base + ["--checkpoint", str(ck), "-o", str(out), str(f)]
+    # with --spill-psa the part files are first written next to GAPFILE and become the checkpoint's part files
+    cmd = base + (["--spill-psa", "-g", str(tmp_path / "gapx")] if spill else []) + ["--checkpoint", str(ck), "-o", str(out), str(f)]
     r = subprocess.run(cmd + ["--stop-after", "2"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 3 and "Process block 2/7" in r.stderr and "Process block 3/7" not in r.stderr, r.stderr[-2000:]
     assert (ck / "ckpt.manifest").exists()
@@ -521,6 +522,7 @@ def test_cli_checkpoint_resume(tmp_path, kind):
     assert out.read_bytes() == ref.read_bytes()
     assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
     assert sorted(os.listdir(ck)) == []
+    assert not [x for x in os.listdir(tmp_path) if x.startswith("gapx")]          # no part file left next to GAPFILE either
 
 
 @pytest.mark.gpu

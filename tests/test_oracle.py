@@ -312,3 +312,73 @@ def test_ref_merge(wd, ref_T):
     assert rc == 0
     assert np.array_equal(mine, out)
     assert np.array_equal(orc.sa5_to_sa(out), sa)
+
+
+def _gt_wrt(isa, n, ref_pos):
+    """bit u <-> position n - u: [text[n-u..) > text[ref_pos..)] (the empty suffix is the smallest)."""
+    return orc.packbits([(isa[n - u] if u > 0 else -1) > (isa[ref_pos] if ref_pos < n else -1) for u in range(n + 1)])
+
+
+def _start_rank_texts():
+    rng = np.random.default_rng(5)
+    return {"rand255": rng.integers(0, 255, 6000, dtype=np.uint8), "sig4z": rng.integers(0, 4, 6000, dtype=np.uint8),
+            "per3": np.frombuffer((b"abc" * 2000)[:6000], np.uint8).copy(), "alla": np.full(4000, 97, np.uint8), "fib": gin.fib()[:6765].copy()}
+
+
+@pytest.mark.parametrize("name", list(_start_rank_texts().keys()))
+def test_initial_rank_restatement_vs_definition(name):
+    """The oracle's start-rank search (K8's checker) against the A.2 definition, with the comparison boundary at the block
+    end (gt w.r.t. the block end: the first overload's rule), behind a mid block (second overload) and at the text end."""
+    t = _start_rank_texts()[name]
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = n // 7, n // 7 + n // 3
+    psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+    tb = e + n // 5
+    pos = sorted(set([e, e + 1, tb, tb + 1, n - 1, n] + list(np.random.default_rng(1).integers(e, n, 40))))
+    for cmp_end in (e, tb, n):
+        gt = None if cmp_end == n else _gt_wrt(isa, n, cmp_end)
+        for p in pos:
+            if p < cmp_end:
+                continue
+            assert orc.initial_rank(t, b, e, psa, cmp_end, gt, int(p)) == r_B(isa, b, e, int(p), n), (name, cmp_end, p)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", list(_start_rank_texts().keys()))
+def test_ref_initial_ranks(name, wd, ref_T):
+    """K8's pin to the reference's own code: em_compute_initial_ranks (both overloads, em_compute_initial_ranks.hpp:222-319 and
+    :513-561, with approx_rank.hpp / sparse_isa.hpp behind the first) == the definition == the oracle's search."""
+    if not hasattr(REF, "ref_initial_ranks"):
+        pytest.skip("oracle/_ref was built before the start-rank wrappers existed")
+    t = _start_rank_texts()[name]
+    n = len(t)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = n // 7, n // 7 + n // 3
+    psa, bwt, i0, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+    psa32 = np.ascontiguousarray(psa, np.int32)
+    for threads, tail_end in ((1, n), (3, n), (7, n), (4, e + (n - e) // 2)):
+        # first overload: chunk starts e + k * ceil(tail / threads); gt w.r.t. e for positions (e, tail_end], bit u <-> tail_end - u
+        gt_full = orc.bits(_gt_wrt(isa, n, e), n + 1)
+        gt = orc.packbits([gt_full[n - (tail_end - u)] for u in range(tail_end - e)] + [0] * 8)
+        out = np.zeros(64, np.int64)
+        after = r_B(isa, b, e, tail_end, n)
+        cnt = REF.ref_initial_ranks(t, n, b, e, psa32, bwt, i0, tail_end, gt.ctypes.data, after, threads, wd, out)
+        S = (tail_end - e + threads - 1) // threads
+        starts = [e + k * S for k in range(cnt)]
+        assert starts[-1] < tail_end
+        want = [r_B(isa, b, e, p, n) for p in starts]
+        assert list(out[:cnt]) == want, (name, threads, tail_end)
+        assert [orc.initial_rank(t, b, e, psa, e, _gt_wrt(isa, n, e), p) for p in starts] == want
+    for threads, tb in ((1, e), (3, e + n // 9), (5, e + n // 4)):
+        # second overload: the text between e and tail_begin is read, gt w.r.t. tail_begin (bit u <-> n - u)
+        gt = _gt_wrt(isa, n, tb)
+        out = np.zeros(64, np.int64)
+        cnt = REF.ref_initial_ranks2(t, n, b, e, psa32, tb, gt.ctypes.data, threads, wd, out)
+        S = (n - tb + threads - 1) // threads
+        starts = [tb + k * S for k in range(cnt)]
+        want = [r_B(isa, b, e, p, n) for p in starts]
+        assert list(out[:cnt]) == want, (name, threads, tb)
+        assert [orc.initial_rank(t, b, e, psa, tb, gt, p) for p in starts] == want
