@@ -81,11 +81,16 @@ def end_to_end_cli(sample_mib, log, api=None, extras=None, english=True, device_
         return {"value": None, "unit": "MB/s", "sample": "failed"}
     peak = [l.strip() for l in r.stderr.splitlines() if "device memory" in l]
     inner = [l.strip() for l in r.stderr.splitlines() if "In-HBM merging" in l]
-    return {"value": n / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "seconds": round(wall, 2), "output_check": "permutation sum ok, 0 sampled pairs out of order",
+    prog = [l.strip() for l in r.stderr.splitlines() if l.strip().startswith("elapsed time:")]
+    prog_s = float(prog[0].split()[2].rstrip("s")) if prog else None
+    return {"value": n / 1e6 / wall, "unit": "MB/s", "host_threads": threads, "host_cpu_count": os.cpu_count(), "seconds": round(wall, 2),
+            "seconds_in_program": prog_s, "value_in_program": (n / 1e6 / prog_s) if prog_s else None,
+            "output_check": "permutation sum ok, 0 sampled pairs out of order",
             "device_memory": peak[0] if peak else None, "leaf_merging": inner[0] if inner else None,
             "sample": f"{sample_mib} MiB {'English-like text' if english else 'uniform bytes 0..254'} from a file, default -m (646 MiB blocks), "
-                      + ("half-blocks sorted on the device (--device-sort, not the reference's placement)" if device_sort else f"half-blocks sorted on {threads} host threads as 1 MiB leaves and merged on the device")
-                      + ", .sa5 written to a file; wall time of the child process"}
+                      + ("half-blocks sorted on the device (--device-sort, not the reference's placement)" if device_sort else
+                         f"the program's default placement: half-blocks suffix-sorted on {threads} host threads as 32 KiB leaves (16-bit partial SAs), merged on the device one tree level per batch of passes")
+                      + f", .sa5 ({5 * n >> 20} MiB) written to a file next to the input; wall time of the child process (process start to exit)"}
 
 
 def parse():
@@ -100,7 +105,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] secondary figure and the CLI sample")
     ap.add_argument("--bwt-hbm", action="store_true", help="configs[2]: keep the BWT and gt_begin of every half-block resident in HBM (default: pinned host memory, uploaded one half-block ahead)")
     ap.add_argument("--psa-hbm-gib", type=float, default=-1.0, help="configs[2]: GiB of partial SAs kept resident in HBM next to the pass temporaries (default: as many half-blocks as fit, sized by an untimed step)")
-    ap.add_argument("--with-output-d2h", action="store_true", help="configs[2]: also time one step with the .sa5 slices copied back to the host")
+    ap.add_argument("--with-output-d2h", action="store_true", help="(default now) configs[2]: also time one step with all partial SAs coming from the host and the .sa5 slices copied back")
+    ap.add_argument("--no-output-d2h", action="store_true", help="configs[2]: skip that extra step")
+    ap.add_argument("--e2e-mib", type=int, default=8192, help="size of the end_to_end_cli sample (default placement of construct_sa), MiB")
     ap.add_argument("--max-chains", type=int, default=0)
     ap.add_argument("--rank-block", type=int, default=0, help="data bytes per rank block (0=auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,7 +193,7 @@ def cpu_baseline(api, extras, sample_mib, log, mode=None):
     detail["sample_sa_bad_pairs"] = bad
     for b in (d_text, Lh["bwt"], Lh["psa_lo"], Lh["gt_begin"], Rh["bwt"], Rh["psa_lo"], Rh["gt_begin"]):
         b.free()
-    return {"value": n / 1e6 / total, "unit": "MB/s", "cores": cores, "kind": kind,
+    return {"value": n / 1e6 / total, "unit": "MB/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": kind,
             "sample": f"{sample_mib} MiB {'English-like text' if mode == extras.MODE_ENGLISH else 'uniform bytes 0..254'}, two {sample_mib // 2} MiB half-blocks: rank build + stream + gap->bitvector + merge, seconds={total:.2f}",
             **detail}
 
@@ -576,14 +583,28 @@ def config2(args, ctx, n, block):
     K = args.steps
     in_use, peak, reserved = api.mem_stats()
     with_d2h = None
-    if args.with_output_d2h:
+    if not args.no_output_d2h:
+        # one more step the way a run behind a host sorter sees it: NO partial SA resident in HBM (all 4 bytes per symbol
+        # come in from pinned host memory during the merge) and every .sa5 slice copied back to the host
+        for v in prepared.values():
+            if v.get("psa_host") is None and v.get("psa_pinned") is not None:
+                v["psa_lo"].free()
+                v["psa_lo"], v["psa_host"] = None, v["psa_pinned"]
         got = [0]
 
         def sink(view, first, cnt):
             got[0] += cnt
-        dt = step(False, sink)
-        with_d2h = {"value": n / 1e6 / dt, "unit": "MB/s", "seconds": round(dt, 3), "entries_received_on_host": got[0],
-                    "note": "same step with every .sa5 slice copied to pinned host memory (5 bytes per suffix over PCIe) and handed to a sink that drops it"}
+        agg_keep = dict(agg)
+        try:
+            dt = step(True, sink)
+            ms = last["ms"]
+            with_d2h = {"value": n / 1e6 / dt, "unit": "MB/s", "seconds": round(dt, 3), "entries_received_on_host": got[0],
+                        "h2d_bytes": int(ms.h2d_bytes), "d2h_bytes": int(ms.d2h_bytes), "partial_sas_resident_in_hbm": 0,
+                        "note": "one step with ALL partial SAs streamed in from pinned host memory (4 bytes per suffix H2D) and every .sa5 slice copied to pinned host "
+                                "memory (5 bytes per suffix D2H) and handed to a sink that drops it: what the schedule costs behind a host sorter, without the file write"}
+        except Exception as ex:
+            with_d2h = {"value": None, "note": f"failed: {ex!r}"}
+        agg.clear(); agg.update(agg_keep)
     suff, kern_s = agg["suffixes"] / K, agg["kernel_ms"] / K / 1e3
     achieved = A_STREAM * suff / kern_s / 1e9 if kern_s > 0 else 0.0
     rankB = [getattr(p[3], "rank_bytes", 0) / (p[2] - p[1]) for p in last["stats"] if p[0] == "B"]
@@ -736,7 +757,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
         if not args.no_secondary:
             try:
-                res["end_to_end_cli"] = end_to_end_cli(2048, log, api, extras, english=args.text == "english")
+                res["end_to_end_cli"] = end_to_end_cli(args.e2e_mib, log, api, extras, english=args.text == "english")
                 res["end_to_end_cli_device_sort"] = end_to_end_cli(2048, log, api, extras, english=args.text == "english", device_sort=True)
             except Exception as e:
                 res["end_to_end_cli"] = {"value": None, "unit": "MB/s", "sample": f"failed: {e!r}"}

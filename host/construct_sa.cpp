@@ -8,10 +8,12 @@
 //                                 adjacent pairs per slice in suffix order); failure = exit status 1
 //                --discard-output produce the .sa5 bytes (they reach host memory) but write no file
 //                --leaf-size N / --fanout F / --no-device-merge
-//                                 half-blocks are suffix-sorted as leaves of <= N symbols on the host cores (1 MiB:
-//                                 the sort stays in the caches) and merged on the device, F sub-ranges at a time --
-//                                 the in-memory pSAscan of the reference (inmem_psascan.hpp:64-304) with the GPU as
-//                                 the merger
+//                                 half-blocks are suffix-sorted as leaves of <= N symbols on the host cores (32 KiB:
+//                                 a leaf stays in a core's L2 and hands over 16-bit positions) and merged on the
+//                                 device, pairwise, every level of the leaf tree in ONE batch of passes
+//                                 (psg_merge_leaves) -- the in-memory pSAscan of the reference
+//                                 (inmem_psascan.hpp:64-304) with the GPU as the merger.  --fanout F: the first
+//                                 version of that merging, F sub-ranges per step and one pass at a time
 //                --device-sort    NOT the reference's placement (north_star keeps the half-block suffix sort on host
 //                                 cores, and that is the default): sort the half-blocks on the device with the
 //                                 bench's prefix-key sorter (psascan_amd_extras.h; texts whose repeats stay below a
@@ -64,6 +66,7 @@
 #include "../include/psascan_amd.h"
 #include "../include/psascan_amd_extras.h"
 #include "halfblock.hpp"
+#include "leafsort.hpp"
 
 using psa_host::HalfBlock;
 
@@ -92,9 +95,10 @@ static void usage(int status) {
          "      --discard-output    do everything but write the output file (extension)\n"
          "      --spill-psa         partial suffix arrays in part files GAPFILE.psa.* instead of host\n"
          "                          memory (extension)\n"
-         "      --leaf-size=N       half-blocks larger than N (default 1Mi) are cut into leaves of at most N\n"
+         "      --leaf-size=N       half-blocks larger than N (default 32Ki) are cut into leaves of at most N\n"
          "                          symbols that are suffix-sorted on the host and merged on the device\n"
-         "      --fanout=F          sub-ranges merged per step of that merging (default 4)\n"
+         "      --fanout=F          merge F sub-ranges per step, one pass at a time (default: pairwise, every\n"
+         "                          level of the leaf tree in one batch of passes; leaves of at most 64Ki)\n"
          "      --no-device-merge   sort every half-block in one piece on the host (extension)\n"
          "      --device-sort       suffix-sort the half-blocks on the device (extension; the default keeps\n"
          "                          the sort on the host cores like the reference)\n"
@@ -175,7 +179,8 @@ struct PendingPsa {
   static void wait_all() { std::lock_guard<std::mutex> lk(mu()); for (PendingPsa *p : all()) p->wait(); }
 };
 
-static void pending_downloads_wait() { PendingPsa::wait_all(); }
+static std::function<void()> g_evict_resident;   // set by run(): moves the partial SAs that were kept in HBM to host memory
+static void pending_downloads_wait() { PendingPsa::wait_all(); if (g_evict_resident) g_evict_resident(); }
 // a library call that allocates its own temporaries: once more after the downloads in flight have released theirs
 template <class F> static int with_memory_retry(F &&f) {
   int rc = f();
@@ -188,9 +193,22 @@ struct DoneHalfBlock {
   int64_t beg = 0, size = 0;
   psa_host::PsaVec psa_lo;
   psa_host::PsaHiVec psa_hi;
+  Dev psa_dev, psa_hi_dev;        // ... or the partial SA stays in HBM (it fits next to everything else: no PCIe round trip)
   Dev mbv;
   std::unique_ptr<PendingPsa> pend;   // psa_lo / psa_hi are still being written (settle() before the host reads them)
   void settle() { if (pend) { pend->wait(); pend.reset(); } }
+  // device memory is short (or the partial SA has to go to a file): the resident copy moves to host memory
+  void to_host() {
+    if (!psa_dev.p) return;
+    psa_lo.resize((size_t)size);
+    if (psg_d2h(psa_lo.data(), psa_dev.p, 4 * size) != 0) throw std::runtime_error(std::string("download of a partial suffix array: ") + psg_last_error());
+    psa_dev.release();
+    if (psa_hi_dev.p) {
+      psa_hi.resize((size_t)size);
+      if (psg_d2h(psa_hi.data(), psa_hi_dev.p, size) != 0) throw std::runtime_error(std::string("download of a partial suffix array: ") + psg_last_error());
+      psa_hi_dev.release();
+    }
+  }
   std::string part_file;          // --spill-psa: [size x u32 low words][size x u8 high bytes, if any]
   bool part_has_hi = false;
   bool keep_part = false;         // checkpointed run: the file outlives this process until the run completes
@@ -205,6 +223,7 @@ struct DoneHalfBlock {
   void drop() { pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
   void take(DoneHalfBlock &o) {
     beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend);
+    psa_dev = std::move(o.psa_dev); psa_hi_dev = std::move(o.psa_hi_dev);
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
     keep_part = o.keep_part;
   }
@@ -227,6 +246,7 @@ struct DoneHalfBlock {
       return;
     }
     settle();
+    to_host();
     part_file = prefix + ".psa." + std::to_string(beg);
     FILE *f = fopen(part_file.c_str(), "wb");
     bool ok = f && fwrite(psa_lo.data(), 4, (size_t)size, f) == (size_t)size;
@@ -265,6 +285,35 @@ struct PlanGuard {
   ~PlanGuard() { if (p) psg_merge_plan_free(p); }
 };
 
+// The .sa5 (5 bytes per symbol) reaches the page cache at ~10.5 GB/s the first time its pages are written and at ~16 GB/s
+// when they are there already (tools/writebench.cpp on the GPU box; parallel writers, O_DIRECT and mmap are all slower).
+// So while the blocks are processed and nothing can be written yet (the first entry of the suffix array is known only
+// after the last block), one helper thread fills the output file with zeros; the merge then overwrites.  It is stopped
+// before the first real byte is written.
+struct OutputPrefill {
+  std::thread th;
+  std::atomic<bool> stop{false};
+  std::atomic<int64_t> done{0};
+  void start(const std::string &fn, int64_t bytes) {
+    th = std::thread([this, fn, bytes]() {
+      const int fd = open(fn.c_str(), O_WRONLY);
+      if (fd < 0) return;
+      const size_t piece = (size_t)32 << 20;
+      std::vector<char> z(piece, 0);
+      int64_t off = 0;
+      while (off < bytes && !stop.load(std::memory_order_relaxed)) {
+        const ssize_t w = pwrite(fd, z.data(), (size_t)std::min<int64_t>((int64_t)piece, bytes - off), (off_t)off);
+        if (w <= 0) break;                                   // (disk full: the real write reports it)
+        off += w;
+        done.store(off, std::memory_order_relaxed);
+      }
+      close(fd);
+    });
+  }
+  void finish() { stop = true; if (th.joinable()) th.join(); }
+  ~OutputPrefill() { finish(); }
+};
+
 struct MappedFile {   // read-only view of the input (the page cache is the host copy of the text)
   const uint8_t *p = nullptr;
   int64_t n = 0;
@@ -300,7 +349,7 @@ static void log_phase(const char *what, double t0, int64_t units = 0) {
 
 struct Options {
   int64_t forced_block = 0, max_chains = 0, check_samples = -1, leaf_size = 0;
-  int fanout = 4;
+  int fanout = 0;                 // 0: leaves merged pairwise, a whole tree level per launch sequence (psg_merge_leaves); >= 2: one pass at a time, F sub-ranges per step
   int64_t tail_chunk = (int64_t)1 << 30;
   bool discard = false, spill_psa = false, hierarchical = true, device_sort = false, text_on_host = false;
   std::string gap_prefix;
@@ -337,8 +386,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   FILE *out = opt.discard ? nullptr : fopen(out_fn.c_str(), "wb");
   if (!opt.discard && !out) throw std::runtime_error("cannot open output " + out_fn);
   if (n == 0) { if (out) fclose(out); return; }
+  OutputPrefill prefill;
+  if (out && n >= ((int64_t)64 << 20) && !getenv("PSASCAN_NO_PREFILL")) prefill.start(out_fn, 5 * n);
 
   CK(psg_init(0));
+  if (g_verbose) fprintf(stderr, "Device initialised after %.2fs\n", wclock() - start);
   char devname[256];
   CK(psg_device_name(devname, sizeof devname));
   fprintf(stderr, "Device = %s\n\n", devname);
@@ -354,12 +406,14 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     opt.device_sort = false;   // the device sorter reads the text up to its end; the leaf merging works through a window per half-block
     fprintf(stderr, "Text stays in host memory: tails are uploaded in chunks of %ld symbols\n\n", (long)opt_in.tail_chunk);
   }
-  Dev d_text = text_on_host ? Dev(16) : upload(text.data(), n);
+  Dev d_text(text_on_host ? 16 : (n + 15) / 16 * 16 + 16, true);   // filled further down, while the host threads sort the first leaves
   Dev tail_buf[2] = {Dev(text_on_host ? opt.tail_chunk + 64 : 16), Dev(text_on_host ? opt.tail_chunk + 64 : 16)};
   const int64_t gt_words = (n + 31) / 32 + 2;
   Dev gt_cur(4 * gt_words, true), gt_new(4 * gt_words, true);
   std::vector<DoneHalfBlock> hbs;
   std::vector<uint32_t> cur_host;
+  g_evict_resident = [&hbs]() { for (DoneHalfBlock &h : hbs) h.to_host(); };
+  struct EvictReset { ~EvictReset() { g_evict_resident = nullptr; } } evict_reset;
 
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
@@ -485,7 +539,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // repeats some stay open: the pass then reports PSG_EUNRESOLVED, the partial SAs of the block's halves are
   // uploaded (they live in host memory) and the pass is repeated with a search context -- the open starts are
   // found by string search over them (em_compute_initial_ranks.hpp:222-319), still in one kernel launch.
-  struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const psa_host::PsaHiVec *hi; DoneHalfBlock *owner; };
+  struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const psa_host::PsaHiVec *hi; DoneHalfBlock *owner; };   // (owner->psa_dev: already on the device)
   auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
                          uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
                          psg_stream_stats *st) {
@@ -535,9 +589,14 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       sc.nparts = (int)parts.size();
       std::vector<Dev> up;
       for (size_t k = 0; k < parts.size(); ++k) {
+        sc.part[k].beg = parts[k].beg; sc.part[k].size = parts[k].size;
+        if (parts[k].owner->psa_dev.p) {                      // kept in HBM
+          sc.part[k].d_psa_lo = parts[k].owner->psa_dev.as<uint32_t>(); sc.part[k].d_psa_hi = parts[k].owner->psa_hi_dev.as<uint8_t>();
+          continue;
+        }
         parts[k].owner->settle();
         up.push_back(upload(parts[k].lo->data(), 4 * parts[k].size));
-        sc.part[k].beg = parts[k].beg; sc.part[k].size = parts[k].size; sc.part[k].d_psa_lo = up.back().as<uint32_t>(); sc.part[k].d_psa_hi = nullptr;
+        sc.part[k].d_psa_lo = up.back().as<uint32_t>(); sc.part[k].d_psa_hi = nullptr;
         if (!parts[k].hi->empty()) { up.push_back(upload(parts[k].hi->data(), parts[k].size)); sc.part[k].d_psa_hi = up.back().as<uint8_t>(); }
       }
       a.flags = PSG_GAP_UNINITIALIZED; a.search = &sc;
@@ -560,10 +619,19 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // in one piece in the sequential schedule, with gt bits from the streaming passes, as in the reference.
   const int64_t LOOKAHEAD_CAP = 1 << 16;
   const bool lookahead = max_threads > 1 && !getenv("PSASCAN_NO_LOOKAHEAD") && !opt.device_sort;
-  const int64_t leaf_size = opt.leaf_size > 0 ? opt.leaf_size : ((int64_t)1 << 20);
-  struct Task { int64_t beg, end; };
+  // Default: leaves of 64 KiB merged in batches.  (The first version -- 1 MiB leaves, four sub-ranges per step, one pass
+  // at a time, still there as --fanout F -- spent 9 of its 12 s per 4 GiB on 4095 device passes of ~2 ms fixed cost, and
+  // smaller leaves, which the host sorts faster, made it slower: 8190 passes.)
+  const bool batched_ok = opt.fanout < 2 && !getenv("PSASCAN_TEST_WIDE_NODES");
+  // 32 KiB: the sorter's two key arrays (16 bytes per symbol) stay inside a core's L2 -- 147 MB/s per core on an EPYC 9575F
+  // against 109 with 64 KiB leaves (tools/leafbench2.cpp), for one more level on the device
+  const int64_t leaf_size = opt.leaf_size > 0 ? opt.leaf_size : (batched_ok ? (int64_t)1 << 15 : (int64_t)1 << 20);
+  const bool batched = batched_ok && leaf_size <= 65536;
+  struct Task { int64_t beg, end, half_ord; };
   std::vector<Task> tasks;                                   // in the order the schedule consumes them
   std::vector<std::vector<int64_t>> half_tasks((size_t)(2 * n_blocks));   // half id -> its task ids, LEFT to RIGHT
+  std::vector<int64_t> half_ord((size_t)(2 * n_blocks), -1);              // half id -> its place in the schedule
+  int64_t n_halves_sched = 0, max_half = 1;
   auto half_range = [&](int64_t id, int64_t &hb_beg, int64_t &hb_end) {
     const int64_t bid = id / 2, b = max_block_size * bid, e = std::min(b + max_block_size, n), bs = e - b;
     const bool last = e == n;
@@ -577,11 +645,14 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       if (he <= hb) continue;
       const int64_t nleaves = lookahead && opt.hierarchical ? std::max<int64_t>(1, (he - hb + leaf_size - 1) / leaf_size) : 1;
       std::vector<int64_t> ids;
+      half_ord[(size_t)(2 * bid + side)] = n_halves_sched;
+      max_half = std::max(max_half, he - hb);
       for (int64_t k = nleaves - 1; k >= 0; --k) {           // rightmost leaf first
-        const int64_t lb = hb + (he - hb) * k / nleaves, le = hb + (he - hb) * (k + 1) / nleaves;
+        const int64_t lb = hb + (__int128)(he - hb) * k / nleaves, le = hb + (__int128)(he - hb) * (k + 1) / nleaves;
         ids.push_back((int64_t)tasks.size());
-        tasks.push_back(Task{lb, le});
+        tasks.push_back(Task{lb, le, n_halves_sched});
       }
+      ++n_halves_sched;
       std::reverse(ids.begin(), ids.end());
       half_tasks[(size_t)(2 * bid + side)] = ids;
     }
@@ -602,20 +673,48 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t phys = pages > 0 && psz > 0 ? (int64_t)pages * psz : ((int64_t)16 << 30);
     window = std::max<int64_t>(2 * max_threads, std::min<int64_t>((int64_t)1 << 16, (phys / 4) / (30 * task_bytes)));
   }
+  // Batched merging: a leaf hands over 16-bit positions only, written straight into the pinned staging buffer of its
+  // half-block (one DMA per half-block later); RING half-blocks may be in the making at a time.
+  const int RING = 3;
+  struct PinnedRing {
+    void *p[3] = {nullptr, nullptr, nullptr};
+    ~PinnedRing() { for (void *q : p) if (q) psg_host_free(q); }
+  } ring;
+  int64_t ring_ready = 0, halves_consumed = 0;   // guarded by pre_mu
+  const bool use_batched = lookahead && opt.hierarchical && batched && max_half < 0xFFFFFFF0ll;
+  if (use_batched) { CK(psg_host_alloc(&ring.p[0], 2 * max_half + 64)); ring_ready = 1; }
   std::vector<std::thread> workers;
   if (lookahead) {
     const long nthreads = std::min<long>(max_threads, (long)tasks.size());
     for (long t = 0; t < nthreads; ++t)
       workers.emplace_back([&]() {
+        psa_host::LeafScratch scratch;
         for (;;) {
           const int64_t k = next_task.fetch_add(1);
           if (k >= (int64_t)tasks.size()) return;
+          const int64_t ord = tasks[(size_t)k].half_ord;
           {
             std::unique_lock<std::mutex> lk(pre_mu);
-            pre_cv.wait(lk, [&] { return stop_workers || k < consumed + window; });
+            if (use_batched) pre_cv.wait(lk, [&] { return stop_workers || ord < halves_consumed + ring_ready; });
+            else pre_cv.wait(lk, [&] { return stop_workers || k < consumed + window; });
             if (stop_workers) return;
           }
           const int64_t hb_beg = tasks[(size_t)k].beg, hb_end = tasks[(size_t)k].end;
+          if (use_batched) {
+            // the half-block this leaf belongs to: the tasks of a half are contiguous, its first position is the begin of
+            // its leftmost leaf = the LAST task of the run with this half_ord
+            int64_t kk = k;
+            while (kk + 1 < (int64_t)tasks.size() && tasks[(size_t)(kk + 1)].half_ord == ord) ++kk;
+            const int64_t half_beg = tasks[(size_t)kk].beg;
+            uint16_t *dst = (uint16_t *)ring.p[ord % RING] + (hb_beg - half_beg);
+            bool ok = false;
+            try { ok = psa_host::sort_leaf16(text.data(), n, hb_beg, hb_end, dst, LOOKAHEAD_CAP, scratch); } catch (...) { ok = false; }
+            if (ok && memchr(text.data() + hb_beg, 255, (size_t)(hb_end - hb_beg))) ok = false;   // reported by the sequential path
+            std::lock_guard<std::mutex> lk(pre_mu);
+            pre[(size_t)k].failed = !ok; pre[(size_t)k].done = true;
+            pre_cv.notify_all();
+            continue;
+          }
           std::unique_ptr<HalfBlock> h;
           bool failed = false;
           try {
@@ -640,6 +739,25 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       for (auto &t : w) if (t.joinable()) t.join();
     }
   } joiner{workers, pre_mu, pre_cv, stop_workers};
+  // the other staging buffers (page-locking 0.65 GiB takes ~0.1 s) on a helper thread, while the first leaves are being
+  // sorted and the text goes up
+  std::thread ring_thread;
+  struct RingJoin { std::thread &t; ~RingJoin() { if (t.joinable()) t.join(); } } ring_join{ring_thread};
+  if (use_batched)
+    ring_thread = std::thread([&]() {
+      for (int r = 1; r < RING && r < n_halves_sched; ++r) {
+        void *q = nullptr;
+        if (psg_host_alloc(&q, 2 * max_half + 64) != 0) return;   // (the run goes on with the buffers it has)
+        std::lock_guard<std::mutex> lk(pre_mu);
+        ring.p[r] = q; ring_ready = r + 1;
+        pre_cv.notify_all();
+      }
+    });
+  if (!text_on_host && n) {
+    const double tu = wclock();
+    CK(psg_h2d(d_text.p, text.data(), n));                     // (the leaf sorters are running by now)
+    if (g_verbose) fprintf(stderr, "Text on the device after %.2fs (upload %.2fs)\n\n", wclock() - start, wclock() - tu);
+  }
   // the pre-sorted leaves of half `id`, left to right; empty when there are none (look-ahead off) or one gave up
   auto take_leaves = [&](int64_t id) -> std::vector<std::unique_ptr<HalfBlock>> {
     std::vector<std::unique_ptr<HalfBlock>> out;
@@ -655,13 +773,40 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     return out;
   };
 
+  // batched merging: wait for the leaves of half `id` (16-bit partial SAs in the half's staging buffer), upload them in
+  // one DMA and release the buffer to the sorters.  false: a leaf gave up (periodic text, byte 255).
+  auto take_staged = [&](int64_t id, Dev &d_leaf, std::vector<int64_t> &bounds) -> bool {
+    const std::vector<int64_t> &ids = half_tasks[(size_t)id];
+    const int64_t ord = half_ord[(size_t)id];
+    bool ok = true;
+    {
+      std::unique_lock<std::mutex> lk(pre_mu);
+      pre_cv.wait(lk, [&] { for (int64_t k : ids) if (!pre[(size_t)k].done) return false; return true; });
+      for (int64_t k : ids) ok = ok && !pre[(size_t)k].failed;
+    }
+    bounds.clear();
+    for (int64_t k : ids) bounds.push_back(tasks[(size_t)k].beg);
+    bounds.push_back(tasks[(size_t)ids.back()].end);
+    const int64_t size = bounds.back() - bounds.front();
+    if (ok) {
+      d_leaf.alloc(2 * size + 64);
+      CK(psg_h2d(d_leaf.p, ring.p[ord % RING], 2 * size));
+    }
+    std::lock_guard<std::mutex> lk(pre_mu);
+    halves_consumed = ord + 1;                                // the staging buffer is free for half ord + RING
+    consumed += (int64_t)ids.size();
+    pre_cv.notify_all();
+    return ok;
+  };
+
   // ---- in-HBM merge of sorted sub-ranges into the partial SA of their union (inmem_psascan.hpp:233-304): the block
   // schedule in small -- sub-range i streams the sub-ranges to its right through its rank structure, the gap array
   // becomes its merge bitvector, one merge yields the union's partial SA; BWT, i0 and gt_begin follow from it.
   // (a node of 2^32 positions or more -- the 8 GiB half-blocks of 16 GiB blocks -- carries bits 32..39 in psa_hi)
   struct DevNode { int64_t beg = 0, size = 0, i0 = 0; Dev psa, psa_hi, bwt, gt; };
   const int64_t wide_from = getenv("PSASCAN_TEST_WIDE_NODES") ? 1 : ((int64_t)1 << 32);   // test hook: every merged node gets a high plane
-  int64_t inner_passes = 0, inner_suffixes = 0;
+  int64_t inner_passes = 0, inner_suffixes = 0, inner_levels = 0;
+  double bt_prepare = 0, bt_rank = 0, bt_search = 0, bt_stream = 0, bt_hist = 0, bt_bv = 0, bt_merge = 0, bt_total = 0;   // batched merging, ms
   double tm_upload = 0, tm_search = 0, tm_rank = 0, tm_stream = 0, tm_bv = 0, tm_merge = 0, tm_finish = 0;   // where the merging spends its time
   psg_search_ctx sc_text{};                                  // comparisons by reading on in the text (cmp_end = n)
   sc_text.d_text = d_text.as<uint8_t>(); sc_text.n = n; sc_text.cmp_end = n; sc_text.d_gt_cmp_end = nullptr; sc_text.nparts = 0;
@@ -680,7 +825,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     sc_text.text_begin = hb; sc_text.text_end = wend;
   };
   auto ckw = [&](int rc, const char *what) {
-    if (rc == PSG_EWINDOW) throw WindowExceeded();
+    if (rc == PSG_EWINDOW || (rc == PSG_EUNRESOLVED && !strcmp(what, "psg_merge_leaves"))) throw WindowExceeded();
     if (rc) throw std::runtime_error(std::string(what) + ": " + psg_last_error());
   };
   auto upload_leaf = [&](HalfBlock &h) {
@@ -766,7 +911,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   };
 
   // one half-block, ready for the block schedule: BWT and gt_begin in HBM, the partial SA in host memory
-  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; psa_host::PsaVec psa_lo; psa_host::PsaHiVec psa_hi; std::vector<uint32_t> gt_host; std::unique_ptr<PendingPsa> pend;
+  struct Half { int64_t beg = 0, size = 0, i0 = 0; Dev bwt, gt; psa_host::PsaVec psa_lo; psa_host::PsaHiVec psa_hi; Dev psa_dev, psa_hi_dev; std::vector<uint32_t> gt_host; std::unique_ptr<PendingPsa> pend;
                 int64_t query_rank = 0; bool have_query_rank = false; };
   auto gt_host_of = [&](Half &h) -> const std::vector<uint32_t> & {   // gt_begin on the host (sequential sorter of the half to the left)
     if (h.gt_host.empty()) { h.gt_host.resize((size_t)((h.size + 31) / 32 + 1)); CK(psg_d2h(h.gt_host.data(), h.gt.p, 4 * (int64_t)h.gt_host.size())); }
@@ -785,6 +930,19 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
         sc.nparts = 1; sc.part[0].beg = hb; sc.part[0].size = H.size; sc.part[0].d_psa_lo = root.psa.as<uint32_t>(); sc.part[0].d_psa_hi = root.psa_hi.as<uint8_t>();
         CK(psg_initial_ranks(&sc, &query_pos, 1, &H.query_rank));
         H.have_query_rank = true;
+      }
+      // A partial SA that fits in HBM next to what the rest of the run needs (~50 bytes per block symbol at the peak of
+      // pass B) stays there: the final merge then reads it where it lies instead of 4-5 bytes per symbol crossing PCIe
+      // twice.  If device memory runs short after all, the resident ones are moved to host memory (g_evict_resident).
+      {
+        int64_t in_use = 0, peak = 0, reserved = 0;
+        psg_mem_stats(&in_use, &peak, &reserved);
+        const int64_t reserve = 50 * max_block_size + ((int64_t)6 << 30);
+        const bool fits = in_use + reserve < (int64_t)(0.92 * (double)dev_total);
+        if (fits && !text_on_host && !opt.spill_psa && !ckpt && !getenv("PSASCAN_PSA_ON_HOST")) {
+          H.psa_dev = std::move(root.psa); H.psa_hi_dev = std::move(root.psa_hi);
+          return;
+        }
       }
       H.psa_lo.resize((size_t)H.size);                        // (default-initialised: the download is the first touch)
       std::unique_ptr<PendingPsa> P(new PendingPsa());
@@ -832,6 +990,47 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       }
       fprintf(stderr, "    device sufsort (%s half) gave up (%s): host sorter\n", what, psg_last_error());
     }
+    if (use_batched) {
+      Dev d_leaf;
+      std::vector<int64_t> bounds;
+      const bool staged = take_staged(id, d_leaf, bounds);
+      const double t_wait = wclock() - t0;
+      bool merged = false;
+      if (staged) {
+        try {
+          set_window(hb, he);
+          DevNode root;
+          root.beg = hb; root.size = H.size;
+          root.psa.alloc(4 * H.size + 16); root.bwt.alloc(H.size + 16); root.gt.alloc(4 * ((H.size + 31) / 32 + 4), true);
+          psg_leaf_merge_stats ls{};
+          ckw(with_memory_retry([&] { return psg_merge_leaves(&sc_text, hb, H.size, bounds.data(), (int64_t)bounds.size() - 1, d_leaf.p, 2, root.psa.as<uint32_t>(),
+                                                              root.bwt.as<uint8_t>(), &root.i0, root.gt.as<uint32_t>(), &ls); }), "psg_merge_leaves");
+          d_leaf.release();
+          inner_passes += ls.passes; inner_suffixes += ls.suffixes; inner_levels += ls.levels;
+          bt_prepare += ls.prepare_ms; bt_rank += ls.rank_ms; bt_search += ls.search_ms; bt_stream += ls.stream_ms; bt_hist += ls.hist_ms; bt_bv += ls.bitvector_ms;
+          bt_merge += ls.merge_ms; bt_total += ls.total_ms;
+          take_root(root);
+          merged = true;
+          fprintf(stderr, "    sufsort (%s half): %zu leaves sorted ahead on the host (waited %.2fs), merged on the device in %.2fs (%ld levels, %ld passes, %.1f Mi suffixes streamed)\n",
+                  what, bounds.size() - 1, t_wait, wclock() - t0 - t_wait, (long)ls.levels, (long)ls.passes, ls.suffixes / 1048576.0);
+        } catch (const WindowExceeded &) {
+          fprintf(stderr, "    sufsort (%s half): a comparison between leaves ran past the text window on the device: host sorter\n", what);
+        }
+        text_window.release();
+      }
+      if (!merged) {                                           // periodic text, long repeats across leaves: one sort with gt bits, as in the reference
+        const double t1 = wclock();
+        HalfBlock h;
+        psa_host::sort_halfblock(text.data(), n, hb, he, gt_tail, h);
+        H.i0 = h.i0;
+        H.bwt = upload(h.bwt.data(), h.size);
+        H.gt = upload(h.gt_begin.data(), 4 * (int64_t)h.gt_begin.size());
+        H.gt_host.swap(h.gt_begin);
+        H.psa_lo.swap(h.psa_lo); H.psa_hi.swap(h.psa_hi);
+        fprintf(stderr, "    host sufsort (%s half): %.2fs (%.2f MiB/s)\n", what, wclock() - t1, H.size / 1048576.0 / std::max(wclock() - t1, 1e-9));
+      }
+      return H;
+    }
     std::vector<std::unique_ptr<HalfBlock>> leaves = take_leaves(id);
     const double t_wait = wclock() - t0;
     auto from_host = [&](HalfBlock &h) {
@@ -874,6 +1073,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     DoneHalfBlock d;
     d.beg = h.beg; d.size = h.size;
     d.psa_lo.swap(h.psa_lo); d.psa_hi.swap(h.psa_hi);
+    d.psa_dev = std::move(h.psa_dev); d.psa_hi_dev = std::move(h.psa_hi_dev);
     d.pend = std::move(h.pend);
     return d;
   };
@@ -885,6 +1085,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t ls = last_block ? std::min<int64_t>(bs, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, bs / 2);
     const int64_t rs = bs - ls, mid = b + ls;
     fprintf(stderr, "Process block %ld/%ld [%ld..%ld):\n", (long)(n_blocks - bid), (long)n_blocks, (long)b, (long)e);
+    if (g_verbose) fprintf(stderr, "    [%.2fs since start]\n", wclock() - start);
     CK(psg_memset(gt_new.p, 0, gt_new.bytes));
     bool have_cur_host = false;
     auto gt_tail_e = [&](int64_t v) {     // [text[e+v..) > text[e..)] from the previous block's passes (fetched when a sequential sort asks)
@@ -988,6 +1189,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   if (inner_passes) {
     fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
     if (g_verbose) fprintf(stderr, "    device allocator: %.2fs in psg_malloc, %.2fs in psg_free (host side)\n", g_alloc_seconds, g_free_seconds);
+    if (g_verbose && inner_levels) fprintf(stderr, "    batched merging: %ld levels, %.2fs in the calls; kernels (ms): leaves -> nodes %.0f, rank builds %.0f, start-rank search %.0f, stream %.0f, "
+                                                   "rank-log histogram %.0f, gap->bitvector %.0f, merge + gt %.0f\n", (long)inner_levels, bt_total / 1e3, bt_prepare, bt_rank, bt_search, bt_stream, bt_hist, bt_bv, bt_merge);
     if (g_verbose) fprintf(stderr, "    seconds: leaf upload %.2f, start-rank search %.2f, rank build %.2f, stream pass %.2f, gap->bitvector %.2f, merge %.2f, BWT/gt from PSA %.2f\n",
                            tm_upload, tm_search, tm_rank, tm_stream, tm_bv, tm_merge, tm_finish);
   }
@@ -996,13 +1199,17 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
 
   // ---- merge (psascan.hpp:117-125, merge.hpp:55-180): PSAs streamed from host memory, .sa5 slices to the file
   fprintf(stderr, "\nMerge partial suffix arrays:\n");
+  prefill.finish();                                          // no zero may land behind a real byte
+  if (g_verbose) fprintf(stderr, "    [%.2fs since start; %.1f of %.1f GiB of the output file were in the page cache ahead of time]\n", wclock() - start,
+                         prefill.done.load() / 1073741824.0, 5.0 * n / 1073741824.0);
   double t0 = wclock();
   std::sort(hbs.begin(), hbs.end(), [](const DoneHalfBlock &a, const DoneHalfBlock &b) { return a.beg < b.beg; });
   std::vector<psg_hb_host_desc> desc(hbs.size());
   for (size_t h = 0; h < hbs.size(); ++h) {
     hbs[h].settle();
     hbs[h].map_back();
-    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr, nullptr, nullptr};
+    desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr,
+                               hbs[h].psa_dev.as<uint32_t>(), hbs[h].psa_hi_dev.as<uint8_t>()};
   }
   struct SinkCtx { FILE *out; bool ok; int64_t entries; } sctx{out, true, 0};
   psg_sink_fn sink = [](void *c, const uint8_t *h_sa5, int64_t, int64_t cnt) -> int {
@@ -1019,7 +1226,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   if (mrc) throw std::runtime_error(std::string("psg_merge_stream: ") + psg_last_error());
   if (sctx.entries != n) throw std::runtime_error("merge produced a wrong number of entries");
   if (out) {   // the last buffer of the .sa5 reaches the disk here: a failure keeps the checkpoint and exits non-zero
-    const bool flushed = fflush(out) == 0 && fsync(fileno(out)) == 0;
+    const bool flushed = fflush(out) == 0;          // (no fsync: 5 bytes per symbol forced to the disk would dominate the run; the reference does not either)
     const bool closed = fclose(out) == 0;
     out = nullptr;
     if (!flushed || !closed) throw std::runtime_error("write failed on " + out_fn);
@@ -1044,6 +1251,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // C library page by page and then run the HIP runtime's teardown of the device arena -- ten seconds after a 32 GiB run.
   for (DoneHalfBlock &h : hbs) if (!h.part_file.empty() && !h.keep_part) remove(h.part_file.c_str());
   fflush(stdout); fflush(stderr);
+  if (getenv("PSASCAN_NORMAL_EXIT")) return;      // under a profiler: its tool library writes its files at a regular exit
   _exit(EXIT_SUCCESS);
 }
 
@@ -1117,5 +1325,6 @@ int main(int argc, char **argv) {
   // everything is written, closed and cleaned up: leave without the HIP runtime's static teardown, which hipFree's
   // the device arena segment by segment (~30 ms per GiB: ten seconds after a 32 GiB run)
   fflush(stdout); fflush(stderr);
+  if (getenv("PSASCAN_NORMAL_EXIT")) return EXIT_SUCCESS;
   _exit(EXIT_SUCCESS);
 }

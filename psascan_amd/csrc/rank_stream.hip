@@ -1194,7 +1194,10 @@ extern "C" int psg_stream_gap_log(const psg_rank_t *r, int64_t i0, int last_sym,
 // the exact hand-over rank: bounds the rank log (8 + 8 GiB) and keeps every chunk in rank-log mode.
 #define PSG_PASS_CHUNK ((int64_t)1 << 31)
 static int stream_impl(const PassArgs &A, int64_t *h_final_rank, psg_stream_stats *stats) {
-  int64_t chunk = PSG_PASS_CHUNK;
+  // (a block below 2^31 symbols -- construct_sa's default -m gives 646 MiB blocks -- takes chunks of 2^29: 390 000 chains
+  // of 1376 steps keep the kernel as busy as longer ones, and the rank log + partition buffers of a chunk are 6 instead
+  // of 24 GiB that the arena has to get from the driver at 25-30 ms per GiB)
+  int64_t chunk = A.r && A.r->m < ((int64_t)1 << 31) ? PSG_PASS_CHUNK >> 2 : PSG_PASS_CHUNK;
   if (const char *e = getenv("PSG_PASS_CHUNK")) { int64_t v = atoll(e); if (v >= 64) chunk = v / 64 * 64; }   // tests
   const i64 T = A.T;
   if (A.log_out || T <= chunk) return stream_chunk(A, h_final_rank, stats);

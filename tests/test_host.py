@@ -395,6 +395,45 @@ def test_cli_leaves_merged_on_the_device(tmp_path, kind, leaf, fanout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,leaf", [("rand", 5000), ("rand", 700), ("sig3", 1000), ("sig3", 40000), ("english", 7777), ("english", 300), ("per3", 5000), ("zeros", 4096),
+                                       ("runs", 2500), ("zeros_mix", 3000)])
+def test_cli_leaves_merged_in_batches(tmp_path, kind, leaf):
+    """the default placement: leaves (16-bit partial SAs only) sorted on the host, merged on the device pairwise with one
+    launch sequence per tree level (psg_merge_leaves).  Every leaf size gives the oracle's suffix array; periodic text makes
+    the leaf sorter give up and takes the sequential path."""
+    rng = np.random.default_rng(leaf)
+    n = 150_001
+    if kind == "rand":
+        t = rng.integers(0, 255, n, dtype=np.uint8)
+    elif kind == "sig3":
+        t = rng.integers(0, 3, n, dtype=np.uint8)
+    elif kind == "zeros_mix":
+        t = np.where(rng.random(n) < 0.4, 0, rng.integers(1, 4, n)).astype(np.uint8)
+    elif kind == "english":
+        words = [b"the", b"of", b"and", b"suffix", b"array", b"block", b"stream", b"gap", b"merge", b"a"]
+        t = np.frombuffer(b" ".join(words[i] for i in rng.integers(0, len(words), 40000)), np.uint8)[:n].copy()
+        n = len(t)
+    elif kind == "per3":
+        t = np.frombuffer((b"abc" * (n // 3 + 1))[:n], np.uint8).copy()
+    elif kind == "zeros":
+        t = np.zeros(n, np.uint8)
+    else:
+        t = np.repeat(rng.integers(0, 5, 8000, dtype=np.uint8), rng.integers(1, 40, 8000))[:n].copy()
+        n = len(t)
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    want = orc.suffix_array(t)
+    for block in (n, 60_000):
+        out = tmp_path / f"x_{block}.sa5"
+        r = subprocess.run([CLI, "-m", "1G", "--block-size", str(block), "--leaf-size", str(leaf), "--check=500", "-v", "-o", str(out), str(f)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), want), (kind, block)
+        if kind in ("rand", "sig3", "english", "zeros_mix") and block == n:
+            assert "levels," in r.stderr and "merged on the device" in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_device_sort_extension(tmp_path):
     """--device-sort (NOT the default placement): half-blocks sorted by the bench's device sorter; periodic text makes it
     give up and fall back to the host sorter.  Same bytes as the default path either way."""
