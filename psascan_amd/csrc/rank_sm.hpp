@@ -8,10 +8,14 @@
 //   LIST   (rare symbols, bucket = 256 positions):
 //            word0 = #c before the bucket ; byte4 = n ; bytes 5..15 = positions (0xFF = unused)
 //            n > 11  ->  byte4 = 0xFF, word2 = index of a 256-bit bitmap in the overflow pool
-//   BITMAP (frequent symbols, bucket = 64 positions):
-//            word0 = #c before the bucket ; words 2,3 = 64-bit occupancy bitmap
-// rank(i, c) = word0 + #positions < (i mod bucket): one sector.  Space = 16 B x (m/256 | m/64) per
+//   BITMAP (frequent symbols, bucket = 96 positions):
+//            word0 = #c before the bucket ; words 1,2,3 = 96-bit occupancy bitmap
+//            (round 2 kept 64 positions per entry and left word 1 unused: a third more table for the same one load --
+//             and the chip's random-sector rate drops with the size of the table, profiles/r02_membench_footprint.txt)
+// rank(i, c) = word0 + #positions < (i mod bucket): one sector.  Space = 16 B x (m/256 | m/96) per
 // symbol: 16 B/symbol of text for a uniform byte alphabet (the block layout with B=32 needs 33).
+// Superblocks (the counts inside the entries are relative to them) and build segments are multiples of
+// lcm(256, 96) = 768 positions, so that no bucket of either kind straddles one.
 // Semantics are those of rank4n<>::rank (rank.hpp:566-568).
 #pragma once
 
@@ -23,7 +27,11 @@
 #define SM_CAP8 4
 #define SM_MODE_SHIFT 62
 #define SM_OFF_MASK ((1ull << SM_MODE_SHIFT) - 1ull)
-#define SM_SEG 4096          // positions per build segment (= seg_hist_kernel<256,64> granularity)
+#define SM_SEG 3072          // positions per build segment: 12 LIST buckets of 256 = 32 BITMAP buckets of 96
+#define SM_LB (SM_SEG / 256) // LIST buckets per segment
+#define SM_BW 96             // positions per BITMAP bucket
+#define SM_BB (SM_SEG / SM_BW)   // BITMAP buckets per segment
+#define SM_SB_SEGS_DEFAULT 699050   // segments per superblock: 3072 * 699050 = 2 147 481 600 < 2^31 (LIST8 keeps bit 31 of its count as a flag)
 #define SM_CAP 11            // positions that fit into a LIST entry
 
 // rank inside a loaded entry: e = E_c[bucket], off = i mod bucket size, t2 = descriptor of the symbol
@@ -43,9 +51,11 @@ __device__ __forceinline__ u32 sm_pool_rank(const u8 *pool, u32 idx, u32 off) { 
 
 __device__ __forceinline__ u32 sm_rank_entry(const uint4 &e, const u8 *pool, u64 t2, u32 off) {
   const u32 mode = (u32)(t2 >> SM_MODE_SHIFT);
-  if (mode == SM_BITMAP) {
-    u64 bm = (u64)e.z | ((u64)e.w << 32);
-    return e.x + (u32)__popcll(bm & ((1ull << off) - 1ull));
+  if (mode == SM_BITMAP) {   // ones below bit `off` (< 96) of the bitmap e.y | e.z << 32 | e.w << 64
+    const u32 m0 = off >= 32 ? 0xFFFFFFFFu : ((1u << off) - 1u);
+    const u32 m1 = off >= 64 ? 0xFFFFFFFFu : (off > 32 ? ((1u << (off - 32)) - 1u) : 0u);
+    const u32 m2 = off > 64 ? ((1u << (off - 64)) - 1u) : 0u;
+    return e.x + (u32)__popc(e.y & m0) + (u32)__popc(e.z & m1) + (u32)__popc(e.w & m2);
   }
   if (mode == SM_LIST8) {   // e.x = count (| 2^31), e.y = four positions or the pool index
     if (e.x & 0x80000000u) return (e.x & 0x7FFFFFFFu) + sm_pool_rank(pool, e.y, off);
@@ -79,18 +89,18 @@ __device__ __forceinline__ u32 sm_eq_nibble(u32 w, u32 c4) {
 // One workgroup per segment of 4096 positions.  Entries are assembled in LDS and written out with
 // neighbouring lanes covering neighbouring entries of the same symbol (128-byte / 1-KiB runs):
 // a thread-per-symbol store pattern would issue 2 G fully divergent 16-byte stores for a 2 GiB BWT.
-#define SM_NB 8                                  // LIST buckets per phase: runs of 8 entries = one full 128-byte line per symbol
+#define SM_NB 6                                  // LIST buckets per phase (two phases per segment): runs of 6 entries = 96 bytes per symbol
 #define SM_OUT_STRIDE (256 + 2)                  // padded so the (symbol, bucket) -> lane transpose reads conflict-free
 struct SmListLds {                               // LIST phase (SM_NB buckets of 256 positions), ~33 KiB -> 4 workgroups per CU
   // slot (bucket j, symbol c): {count, 12 position bytes}; rewritten IN PLACE into the finished entry
   uint4 slot[SM_NB * SM_OUT_STRIDE];
 };
-struct SmList8Lds {                              // LIST8 phase: all 16 buckets of the segment at once, 8-byte slots (~33 KiB)
-  uint2 slot[16 * SM_OUT_STRIDE];                // {count, 4 position bytes} -> the finished entry, in place
+struct SmList8Lds {                              // LIST8 phase: all 12 buckets of the segment at once, 8-byte slots (~25 KiB)
+  uint2 slot[SM_LB * SM_OUT_STRIDE];             // {count, 4 position bytes} -> the finished entry, in place
 };
-struct SmBitmapLds {                             // BITMAP phase (64 sub-buckets of 64)
-  u64 bm[SM_MAX_BITMAP * 64];
-  u32 cum[SM_MAX_BITMAP * 64];
+struct SmBitmapLds {                             // BITMAP phase (32 sub-buckets of 96)
+  u32 b0[SM_MAX_BITMAP * SM_BB], b1[SM_MAX_BITMAP * SM_BB], b2[SM_MAX_BITMAP * SM_BB];
+  u32 cum[SM_MAX_BITMAP * SM_BB];
 };
 union SmPhaseLds { SmListLds L; SmList8Lds L8; SmBitmapLds B; };
 
@@ -135,17 +145,17 @@ __device__ __forceinline__ void sm_dense_flush(SmDense &D, const u8 *sym, i64 ba
   if (threadIdx.x == 0) D.n = 0;
 }
 
-// occurrences of every symbol before superblock sb (superblock = 2^sbs segments): workgroup sb, thread c
-__global__ __launch_bounds__(256) void sm_sb_base_kernel(const u32 *seg_pref, const u64 *group_base, int sbs, u64 *sb_base) {
-  const i64 seg0 = (i64)blockIdx.x << sbs;
+// occurrences of every symbol before superblock sb (superblock = sbs segments): workgroup sb, thread c
+__global__ __launch_bounds__(256) void sm_sb_base_kernel(const u32 *seg_pref, const u64 *group_base, i64 sbs, u64 *sb_base) {
+  const i64 seg0 = (i64)blockIdx.x * sbs;
   sb_base[(i64)blockIdx.x * 256 + threadIdx.x] = group_base[(seg0 / GROUP_SEGS) * 256 + threadIdx.x] + seg_pref[seg0 * 256 + threadIdx.x];
 }
 
 // L8: the LIST symbols of this structure use 8-byte entries (SM_LIST8) -- all of them or none
-// sbs: log2(segments per superblock); the counts stored in the entries are relative to the superblock start
+// sbs: segments per superblock; the counts stored in the entries are relative to the superblock start
 template <bool L8>
 __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, const u64 *t2g, const u32 *seg_pref, const u64 *group_base,
-                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err, int sbs) {
+                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err, i64 sbs) {
   __shared__ __attribute__((aligned(16))) u8 sym[SM_SEG];
   __shared__ __attribute__((aligned(16))) SmPhaseLds P;
   __shared__ u64 t2S[256];
@@ -159,19 +169,19 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
   t2S[c] = t2;
   if (c == 0) { nbm = 0; D.n = 0; }
   if (base + SM_SEG <= m && ((uintptr_t)bwt & 15) == 0) {
-    ((uint4 *)sym)[c] = ((const uint4 *)(bwt + base))[c];
+    if (c < SM_SEG / 16) ((uint4 *)sym)[c] = ((const uint4 *)(bwt + base))[c];
   } else {
     for (int k = c; k < SM_SEG; k += 256) sym[k] = base + k < m ? bwt[base + k] : 0;
   }
   __syncthreads();
   if (mymode == SM_BITMAP) { int k = atomicAdd(&nbm, 1); if (k < SM_MAX_BITMAP) bmSym[k] = (u8)c; }
-  const i64 seg0 = (seg >> sbs) << sbs;   // first segment of this superblock
+  const i64 seg0 = seg / sbs * sbs;       // first segment of this superblock
   u32 run = (u32)(group_base[(seg / GROUP_SEGS) * 256 + c] + seg_pref[seg * 256 + c] - (group_base[(seg0 / GROUP_SEGS) * 256 + c] + seg_pref[seg0 * 256 + c]));
-  // ---------------- LIST8 symbols: one phase over the 16 buckets, runs of 16 entries = one 128-byte line ----------------
+  // ---------------- LIST8 symbols: one phase over the 12 buckets, runs of 12 entries = 96 bytes ----------------
   if (L8) {
-    for (int k = c; k < 16 * SM_OUT_STRIDE; k += 256) P.L8.slot[k] = make_uint2(0u, ~0u);
+    for (int k = c; k < SM_LB * SM_OUT_STRIDE; k += 256) P.L8.slot[k] = make_uint2(0u, ~0u);
     __syncthreads();
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < SM_LB; ++j) {
       int q = j * 256 + c;
       if (base + q < m) {
         u32 s = sym[q];
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
     }
     __syncthreads();
     if (mymode == SM_LIST8) {
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < SM_LB; ++j) {
         const uint2 raw = P.L8.slot[j * SM_OUT_STRIDE + c];
         const u32 n = raw.x;
         uint2 e = make_uint2(run, raw.y);
@@ -198,16 +208,16 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
       }
     }
     sm_dense_flush(D, sym, base, m, 0, pool, pool_cursor, pool_cap, err, [&](int j, int cc, u32 idx) { P.L8.slot[j * SM_OUT_STRIDE + cc].y = idx; });
-    for (int idx = c; idx < 256 * 16; idx += 256) {   // 16 consecutive lanes write the 16 entries of one symbol
-      int s = idx >> 4, j = idx & 15;
+    for (int idx = c; idx < 256 * SM_LB; idx += 256) {   // 12 consecutive lanes write the 12 entries of one symbol
+      int s = idx / SM_LB, j = idx % SM_LB;
       u64 ts = t2S[s];
-      i64 bk = seg * 16 + j;
+      i64 bk = seg * SM_LB + j;
       if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST8 && bk * 256 < m) ((uint2 *)(entries + (ts & SM_OFF_MASK)))[bk] = P.L8.slot[j * SM_OUT_STRIDE + s];
     }
     __syncthreads();
   }
-  // ---------------- LIST symbols: 16/SM_NB phases of SM_NB buckets ----------------
-  for (int ph = 0; !L8 && ph < 16 / SM_NB; ++ph) {
+  // ---------------- LIST symbols: SM_LB/SM_NB phases of SM_NB buckets ----------------
+  for (int ph = 0; !L8 && ph < SM_LB / SM_NB; ++ph) {
     for (int k = c; k < SM_NB * SM_OUT_STRIDE; k += 256) P.L.slot[k] = make_uint4(0u, ~0u, ~0u, ~0u);
     __syncthreads();
     for (int j = 0; j < SM_NB; ++j) {
@@ -245,35 +255,42 @@ __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, cons
     for (int idx = c; idx < 256 * SM_NB; idx += 256) {   // SM_NB consecutive lanes write consecutive entries of one symbol
       int s = idx / SM_NB, j = idx % SM_NB;
       u64 ts = t2S[s];
-      i64 bk = seg * 16 + ph * SM_NB + j;
+      i64 bk = seg * SM_LB + ph * SM_NB + j;
       if ((u32)(ts >> SM_MODE_SHIFT) == SM_LIST && bk * 256 < m) entries[(ts & SM_OFF_MASK) + bk] = P.L.slot[j * SM_OUT_STRIDE + s];
     }
     __syncthreads();
   }
-  // ---------------- BITMAP symbols: (symbol, sub-bucket) items ----------------
+  // ---------------- BITMAP symbols: (symbol, sub-bucket of 96 positions) items ----------------
   const int nb = nbm < SM_MAX_BITMAP ? nbm : SM_MAX_BITMAP;
-  for (int item = c; item < nb * 64; item += 256) {
-    int s = bmSym[item >> 6], sub = item & 63;
-    const u32 *ws = (const u32 *)(sym + sub * 64);
+  for (int item = c; item < nb * SM_BB; item += 256) {
+    int s = bmSym[item / SM_BB], sub = item % SM_BB;
+    const u32 *ws = (const u32 *)(sym + sub * SM_BW);
     u32 s4 = (u32)s * 0x01010101u;
-    u64 bm = 0;
+    u32 b[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int w = 0; w < 16; ++w) bm |= (u64)sm_eq_nibble(ws[w], s4) << (4 * w);
-    i64 lim = m - (base + sub * 64);
-    if (lim < 64) bm &= lim <= 0 ? 0ull : ((1ull << lim) - 1ull);
-    P.B.bm[item] = bm;
+    for (int w = 0; w < SM_BW / 4; ++w) b[w >> 3] |= sm_eq_nibble(ws[w], s4) << (4 * (w & 7));
+    i64 lim = m - (base + sub * SM_BW);       // valid positions of this sub-bucket
+    if (lim < SM_BW) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const i64 l = lim - 32 * k; if (l < 32) b[k] &= l <= 0 ? 0u : ((1u << l) - 1u); }
+    }
+    P.B.b0[item] = b[0]; P.B.b1[item] = b[1]; P.B.b2[item] = b[2];
   }
   __syncthreads();
-  if (mymode == SM_BITMAP) {   // running counts over the 64 sub-buckets of this symbol
+  if (mymode == SM_BITMAP) {   // running counts over the sub-buckets of this symbol
     int k = 0;
     while (k < nb && bmSym[k] != c) ++k;
-    if (k < nb) for (int sub = 0; sub < 64; ++sub) { P.B.cum[k * 64 + sub] = run; run += (u32)__popcll(P.B.bm[k * 64 + sub]); }
+    if (k < nb)
+      for (int sub = 0; sub < SM_BB; ++sub) {
+        const int it = k * SM_BB + sub;
+        P.B.cum[it] = run;
+        run += (u32)__popc(P.B.b0[it]) + (u32)__popc(P.B.b1[it]) + (u32)__popc(P.B.b2[it]);
+      }
   }
   __syncthreads();
-  for (int item = c; item < nb * 64; item += 256) {
-    int s = bmSym[item >> 6], sub = item & 63;
-    i64 bk = seg * (SM_SEG / 64) + sub;
-    u64 bm = P.B.bm[item];
-    if (bk * 64 < m) entries[(t2S[s] & SM_OFF_MASK) + bk] = make_uint4(P.B.cum[item], 0u, (u32)bm, (u32)(bm >> 32));
+  for (int item = c; item < nb * SM_BB; item += 256) {
+    int s = bmSym[item / SM_BB], sub = item % SM_BB;
+    i64 bk = seg * SM_BB + sub;
+    if (bk * SM_BW < m) entries[(t2S[s] & SM_OFF_MASK) + bk] = make_uint4(P.B.cum[item], P.B.b0[item], P.B.b1[item], P.B.b2[item]);
   }
 }

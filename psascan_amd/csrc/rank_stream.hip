@@ -37,7 +37,8 @@ struct psg_rank {
   int cnt = 0, B = 0, stride = 0;
   i64 nblk = 0, nseg = 0;
   int nsb = 0;
-  int sb_shift = 0;               // log2(positions per superblock) (symbol-major) / log2(blocks per superblock) (interleaved blocks)
+  int sb_shift = 0;               // interleaved blocks: log2(blocks per superblock)
+  i64 sb_size = 0;                // symbol-major: positions per superblock (a multiple of SM_SEG = 3072: not a power of two)
   u8 *d_blocks = nullptr;
   i64 blocks_bytes = 0;
   u64 *d_sb = nullptr;            // [nsb][cnt]
@@ -127,7 +128,8 @@ template <int CNT, int B> struct RankView {   // CNT == 0: symbol-major layout (
   const u8 *blocks;
   i64 m;
   const u8 *aux;                                     // symbol-major layout: overflow bitmap pool
-  int sb_shift;                                      // log2(positions | blocks per superblock)
+  int sb_shift;                                      // interleaved blocks: log2(blocks per superblock)
+  i64 sb_size;                                       // symbol-major: positions per superblock
   static constexpr int STRIDE = 4 * CNT + B;
   static constexpr int MID = B == 48 ? 32 : B / 2;   // multiple of 16, >= B - MID
 };
@@ -156,7 +158,9 @@ template <int CNT, int B> struct RankReq {
 template <int CNT, int B>
 __device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 *T1, const u64 *tot, i64 i, u32 c, RankReq<CNT, B> &q) {
   // symbol-major layout: the entry's count is relative to the superblock of i, whose base is folded into T1
-  const i64 sbi = (CNT == 0 && i > 0 && i < R.m) ? (i >> R.sb_shift) : 0;
+  i64 sbi = 0;
+  if (CNT == 0 && i > 0 && i < R.m)
+    for (i64 t = R.sb_size; t <= i; t += R.sb_size) ++sbi;   // (one to three superblocks in practice: blocks of up to 2^32+ symbols)
   u64 e0 = T1[sbi * 256 + c];
   u32 code = (u32)(e0 >> CODE_SHIFT);
   i64 Cc = (i64)(e0 & VAL_MASK);
@@ -170,9 +174,10 @@ __device__ __forceinline__ void rank_issue(const RankView<CNT, B> &R, const u64 
     if (mode == SM_ABSENT) return;
     const uint4 *E = (const uint4 *)R.blocks + (t2 & SM_OFF_MASK);
     bool bm = mode == SM_BITMAP;
+    const u32 b96 = (u32)(((u64)(u32)(i >> 5) * 0xAAAAAAABull) >> 33);   // i / 96 (i < 2^37)
     if (mode == SM_LIST8) { uint2 x = ((const uint2 *)E)[i >> 8]; q.e = make_uint4(x.x, x.y, 0u, 0u); }
-    else q.e = E[bm ? (i >> 6) : (i >> 8)];
-    q.off = (u32)i & (bm ? 63u : 255u);
+    else q.e = E[bm ? (i64)b96 : (i >> 8)];
+    q.off = bm ? (u32)(i - (i64)b96 * SM_BW) : ((u32)i & 255u);
     q.t2 = t2;
     q.kind = 1;
   } else {
@@ -366,6 +371,31 @@ __global__ __launch_bounds__(PSG_WG) void rank_fill_kernel(const u8 *bwt, i64 m,
     if (gb >= nblk) continue;
     *(u32 *)(blocks + gb * STRIDE + 4 * CNT + o) = *(const u32 *)(sym + k * 4);
   }
+}
+
+// per-segment symbol histograms of the symbol-major build (segments of SM_SEG positions)
+__global__ __launch_bounds__(PSG_WG) void sm_seg_hist_kernel(const u8 *bwt, i64 m, u32 *seg_cnt) {
+  constexpr int CP = 8;                              // copies of the histogram (see hist256_kernel)
+  __shared__ u32 h[256 * CP];
+  for (int k = threadIdx.x; k < 256 * CP; k += PSG_WG) h[k] = 0;
+  __syncthreads();
+  const u32 cp = threadIdx.x & (CP - 1);
+  const i64 base = (i64)blockIdx.x * SM_SEG;
+  if (base + SM_SEG <= m && ((uintptr_t)bwt & 15) == 0) {
+    if (threadIdx.x < SM_SEG / 16) {
+      const uint4 v = ((const uint4 *)(bwt + base))[threadIdx.x];
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) atomicAdd(&h[((w[k >> 2] >> (8 * (k & 3))) & 255u) * CP + cp], 1u);
+    }
+  } else {
+    for (int k = threadIdx.x; k < SM_SEG; k += PSG_WG) if (base + k < m) atomicAdd(&h[(u32)bwt[base + k] * CP + cp], 1u);
+  }
+  __syncthreads();
+  u32 tot = 0;
+#pragma unroll
+  for (int q = 0; q < CP; ++q) tot += h[threadIdx.x * CP + ((q + threadIdx.x) & (CP - 1))];
+  seg_cnt[(i64)blockIdx.x * 256 + threadIdx.x] = tot;
 }
 
 // LDS table loader shared by the query / warm-up / stream kernels
@@ -720,9 +750,12 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   *fell_back = true;
   // counts inside the entries are relative to superblocks of 2^31 positions (LIST8 keeps bit 31 of the count as
   // its "dense bucket" flag); PSG_SM_SB_SHIFT makes them small so that tests run several superblocks
-  int sb_shift = 31;
-  if (const char *e = getenv("PSG_SM_SB_SHIFT")) { int v = atoi(e); if (v >= 12 && v <= 31) sb_shift = v; }
-  const int nsb = (int)(((m - 1) >> sb_shift) + 1);
+  // superblocks: multiples of the build segment (3072 = 12 LIST buckets = 32 BITMAP buckets), just under 2^31 positions
+  i64 sb_segs = SM_SB_SEGS_DEFAULT;
+  if (const char *e = getenv("PSG_SM_SB_SHIFT")) { int v = atoi(e); if (v >= 12 && v < 31) sb_segs = (i64)1 << (v - 12); }
+  const i64 sb_size = sb_segs * SM_SEG;
+  if ((m - 1) / sb_size + 1 > 64) return 0;
+  const int nsb = (int)((m - 1) / sb_size + 1);
   if (nsb > 64) return 0;   // LDS table of the pass: 2 KiB per superblock
   // per-symbol mode: BITMAP (bucket 64) when a 256-bucket would hold > 3 occurrences on average; the other
   // symbols get 8-byte LIST8 entries (4 positions inline) if every one of them averages <= 1.5 per bucket
@@ -746,7 +779,7 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   for (int c = 0; c < 256; ++c) {
     if (!h[c]) { t2[c] = 0; continue; }
     bool bitmap = (double)h[c] * 256.0 > 3.0 * (double)m;
-    u64 nbk = bitmap ? (u64)cdiv(m, 64) : (u64)cdiv(m, 256);
+    u64 nbk = bitmap ? (u64)cdiv(m, SM_BW) : (u64)cdiv(m, 256);
     if (!bitmap && list8) nbk = (nbk + 1) / 2;   // 8-byte entries, counted in 16-byte units
     t2[c] = off16 | ((u64)(bitmap ? SM_BITMAP : (list8 ? SM_LIST8 : SM_LIST)) << SM_MODE_SHIFT);
     off16 += (nbk + 7) / 8 * 8;   // regions start on 128-byte lines (the fill kernel writes whole lines)
@@ -769,14 +802,14 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
     return fail(rc);
   if ((rc = psg::copy_h2d(code_d.p, ident, 256)) || (rc = psg::copy_h2d(t2_d.p, t2, sizeof t2))) return fail(rc);
   if (hipMemsetAsync(misc.p, 0, 8, stream()) != hipSuccess) { set_error("sm_build: memset failed"); return fail(PSG_EDEVICE); }
-  hipLaunchKernelGGL((seg_hist_kernel<256, 64>), dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, code_d.as<u8>(), seg_cnt.as<u32>());
+  hipLaunchKernelGGL(sm_seg_hist_kernel, dim3((unsigned)nseg), dim3(PSG_WG), 0, stream(), d_bwt, m, seg_cnt.as<u32>());
   hipLaunchKernelGGL(group_prefix_kernel, dim3((unsigned)cdiv(ngroups * 256, PSG_WG)), dim3(PSG_WG), 0, stream(), seg_cnt.as<u32>(), nseg, 256, group_sum.as<u64>(), ngroups);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
-  hipLaunchKernelGGL(sm_sb_base_kernel, dim3((unsigned)nsb), dim3(256), 0, stream(), seg_cnt.as<u32>(), group_sum.as<u64>(), sb_shift - 12, sb_d.as<u64>());
+  hipLaunchKernelGGL(sm_sb_base_kernel, dim3((unsigned)nsb), dim3(256), 0, stream(), seg_cnt.as<u32>(), group_sum.as<u64>(), sb_segs, sb_d.as<u64>());
   if (list8) hipLaunchKernelGGL(sm_fill_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_shift - 12);
+                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs);
   else hipLaunchKernelGGL(sm_fill_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_shift - 12);
+                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs);
   u32 st[2] = {0, 0};
   hipError_t e4 = hipGetLastError();
   if (e4 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4)); return fail(PSG_EDEVICE); }
@@ -788,7 +821,7 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   }
   r->h_sb.assign((size_t)nsb * 256, 0);
   if ((rc = psg::copy_d2h(r->h_sb.data(), sb_d.p, (size_t)nsb * 256 * 8))) return fail(rc);
-  r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = nsb; r->sb_shift = sb_shift;
+  r->cnt = 0; r->B = 0; r->stride = 0; r->nblk = 0; r->nseg = nseg; r->nsb = nsb; r->sb_shift = 0; r->sb_size = sb_size;
   r->d_blocks = entries; r->d_aux = pool; r->blocks_bytes = entries_bytes + (i64)pool_cap * 32;
   for (int c = 0; c < 256; ++c) { r->t2[c] = t2[c]; r->code[c] = (u8)c; }
   *fell_back = false;
@@ -933,7 +966,7 @@ static int make_tables(const psg_rank *r, const i64 *Cadd, DevBuf &T1, DevBuf &t
 
 template <int CNT, int B>
 static void launch_query(const psg_rank *r, const u64 *T1, const u64 *tot, const i64 *qi, const u8 *qc, i64 nq, i64 *out) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift, r->sb_size};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((rank_query_kernel<CNT, B>), dim3((unsigned)cdiv(nq, PSG_WG)), dim3(PSG_WG), lds, stream(), R, T1, tot,
                      r->nsb, qi, qc, nq, out);
@@ -951,7 +984,7 @@ extern "C" int psg_rank_query(const psg_rank_t *r, const int64_t *d_i, const uin
 }
 
 template <int CNT, int B> static void launch_warm(const psg_rank *r, WarmParams P) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift, r->sb_size};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((warmup_kernel<CNT, B>), dim3((unsigned)cdiv(P.nitems, PSG_WG)), dim3(PSG_WG), lds, stream(), R, P);
 }
@@ -963,7 +996,7 @@ static int chains_per_lane(const psg_rank *r) {
   return 1;   // measured (MI355X, 4 GiB bench): 2 chains/lane at 4 waves/SIMD == 1 chain/lane at 8 waves/SIMD
 }
 template <int CNT, int B> static void launch_stream(const psg_rank *r, StreamParams P, int mode, int cpl) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift, r->sb_size};
   size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   dim3 grid((unsigned)cdiv(cdiv(P.nchains, cpl), PSG_WG));
 #define PSG_LAUNCH(MODE_)                                                                                          \
@@ -1032,7 +1065,7 @@ __global__ __launch_bounds__(256) void batch_setup_kernel(RankView<CNT, B> R, co
 template <int CNT, int B>
 static void launch_batch_setup(const psg_rank *r, psg::BatchTables *t, const psg::BatchGeom *geom, i64 npass, const i64 *i0_nodes, const u8 *text, const u32 *gt_cur,
                                u32 *gt_new, i64 L, i64 *init, i64 *fin, u32 *log, i64 Ktotal, u32 *gap, psg::GapExcess ex) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift, r->sb_size};
   const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   hipLaunchKernelGGL((batch_setup_kernel<CNT, B>), dim3((unsigned)npass), dim3(256), lds, stream(), R, t->T1g.as<u64>(), t->tot.as<u64>(), r->nsb, geom, i0_nodes, text,
                      gt_cur, gt_new, L, init, fin, log, Ktotal, gap, ex, t->T1p.as<u64>(), t->passes.as<StreamParams>());
@@ -1046,7 +1079,7 @@ int psg::stream_batch_setup(const psg_rank_t *r, BatchTables *t, const BatchGeom
 }
 template <int CNT, int B>
 static void launch_stream_batch(const psg_rank *r, const psg::BatchTables *t, const u32 *wg_pass, const u32 *wg_local, i64 nwg, int mode) {
-  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift};
+  RankView<CNT, B> R{r->d_blocks, r->m, r->d_aux, r->sb_shift, r->sb_size};
   const size_t lds = ((size_t)r->nsb * 256 + 512) * 8;
   const dim3 grid((unsigned)nwg);
   const StreamParams *passes = t->passes.as<StreamParams>();
