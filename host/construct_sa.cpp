@@ -27,6 +27,13 @@
 //                                 pass uploads its tail in chunks of N symbols (default 1 Gi) and streams them one
 //                                 after the other with the exact hand-over rank -- stream.hpp:104-106 reads the tail
 //                                 from the text file the same way
+//                --hbm-limit N    the external-memory schedule with HBM in the place of the reference's RAM budget: the
+//                                 library hands out at most N bytes of device memory (psg_set_memory_limit); the text
+//                                 stays in host memory (tails uploaded chunk by chunk), so do the gt bits (a chunk's
+//                                 words go up and come back with it: stream.hpp:104-106 reads and writes them through
+//                                 files), the partial SAs, and every finished merge bitvector (psg_mbv_spill; the
+//                                 reference's gap files, gap_array.hpp:156-182) -- the merge streams all of them back
+//                                 slice by slice (merge.hpp:72-81,143-145)
 //                --spill-psa      keep the partial suffix arrays in part files next to GAPFILE (-g; default: the
 //                                 output name) instead of host memory: `GAPFILE.psa.<beg>` is written when a block
 //                                 is done and mapped back for the merge (the reference's distributed_file,
@@ -105,6 +112,10 @@ static void usage(int status) {
          "      --checkpoint=DIR    keep the state of the run in DIR after every block (partial SAs, merge\n"
          "                          bitvectors, gt bits); a run started again with the same arguments resumes\n"
          "                          behind the last finished block (the reference starts over)\n"
+         "      --hbm-limit=N       use at most N bytes of device memory: the text, the gt bits, the partial suffix\n"
+         "                          arrays and the finished merge bitvectors then live in host memory and pass\n"
+         "                          through the device piece by piece (the external-memory schedule of the\n"
+         "                          reference with HBM in the place of RAM; blocks need ~50 bytes per symbol)\n"
          "      --text-on-host      keep the text in host memory and upload the tail of every pass in chunks\n"
          "                          (automatic for texts beyond 55%% of the device memory); --tail-chunk=N\n",
          program_name);
@@ -195,6 +206,16 @@ struct DoneHalfBlock {
   psa_host::PsaHiVec psa_hi;
   Dev psa_dev, psa_hi_dev;        // ... or the partial SA stays in HBM (it fits next to everything else: no PCIe round trip)
   Dev mbv;
+  int64_t mbv_bits = 0;           // length of the merge bitvector
+  std::vector<uint32_t> mbv_host; // --hbm-limit: the merge bitvector lives in host memory (psg_mbv_spill) ...
+  std::vector<uint64_t> mbv_samp; // ... with its rank samples
+  void spill_mbv() {
+    if (!mbv.p || mbv_bits <= 0) return;
+    mbv_host.resize((size_t)psg_mbv_spill_words(mbv_bits));
+    mbv_samp.resize((size_t)((mbv_bits + 4095) / 4096 + 1));
+    if (psg_mbv_spill(mbv.as<uint32_t>(), mbv_bits, mbv_host.data(), mbv_samp.data()) != 0) throw std::runtime_error(std::string("psg_mbv_spill: ") + psg_last_error());
+    mbv.release();
+  }
   std::unique_ptr<PendingPsa> pend;   // psa_lo / psa_hi are still being written (settle() before the host reads them)
   void settle() { if (pend) { pend->wait(); pend.reset(); } }
   // device memory is short (or the partial SA has to go to a file): the resident copy moves to host memory
@@ -224,6 +245,7 @@ struct DoneHalfBlock {
   void take(DoneHalfBlock &o) {
     beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend);
     psa_dev = std::move(o.psa_dev); psa_hi_dev = std::move(o.psa_hi_dev);
+    mbv_bits = o.mbv_bits; mbv_host = std::move(o.mbv_host); mbv_samp = std::move(o.mbv_samp);
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
     keep_part = o.keep_part;
   }
@@ -353,6 +375,7 @@ struct Options {
   int64_t tail_chunk = (int64_t)1 << 30;
   bool discard = false, spill_psa = false, hierarchical = true, device_sort = false, text_on_host = false;
   std::string gap_prefix;
+  int64_t hbm_limit = 0;          // --hbm-limit N: the device hands out at most N bytes; what does not fit lives in host memory
   std::string checkpoint_dir;     // --checkpoint DIR: state on disk after every block; an interrupted run resumes from it
   int64_t stop_after = 0;         // test hook: stop (exit status 3) after this many blocks of this invocation
 };
@@ -398,18 +421,52 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // symbol of temporaries).  A text that would take more than 55 % of the device (or --text-on-host) stays in host
   // memory: every pass then uploads its tail in chunks and streams chunk after chunk with the exact hand-over rank
   // (the reference reads the tail from the text file in every pass, stream.hpp:104-106).
+  if (opt.hbm_limit > 0) {
+    CK(psg_set_memory_limit(opt.hbm_limit));
+    fprintf(stderr, "Device memory budget = %ld (%.1fMiB): the text, the gt bits, the partial suffix arrays and the finished merge bitvectors live in host memory\n\n",
+            (long)opt.hbm_limit, opt.hbm_limit / 1048576.0);
+    if (48 * (double)max_block_size > (double)opt.hbm_limit)
+      throw std::runtime_error("the blocks are too large for --hbm-limit: a block of " + std::to_string(max_block_size) + " symbols needs ~50 bytes of device memory per symbol (use a smaller -m)");
+  }
   int64_t dev_free = 0, dev_total = 0;
   CK(psg_device_memory(&dev_free, &dev_total));
-  const bool text_on_host = opt_in.text_on_host || (double)n > 0.55 * (double)dev_total;
+  const bool text_on_host = opt_in.text_on_host || opt.hbm_limit > 0 || (double)n > 0.55 * (double)dev_total;
+  const bool host_tier = opt.hbm_limit > 0;      // gt bits and merge bitvectors in host memory as well
   if (text_on_host) {
-    if (opt_in.check_samples >= 0) throw std::runtime_error("--check needs the text in HBM (not with --text-on-host / a text beyond 55 % of the device memory)");
     opt.device_sort = false;   // the device sorter reads the text up to its end; the leaf merging works through a window per half-block
     fprintf(stderr, "Text stays in host memory: tails are uploaded in chunks of %ld symbols\n\n", (long)opt_in.tail_chunk);
   }
   Dev d_text(text_on_host ? 16 : (n + 15) / 16 * 16 + 16, true);   // filled further down, while the host threads sort the first leaves
   Dev tail_buf[2] = {Dev(text_on_host ? opt.tail_chunk + 64 : 16), Dev(text_on_host ? opt.tail_chunk + 64 : 16)};
   const int64_t gt_words = (n + 31) / 32 + 2;
-  Dev gt_cur(4 * gt_words, true), gt_new(4 * gt_words, true);
+  // gt bits of every position behind the current block w.r.t. its begin (bit n - j), the reference's tail_gt_begin_rev
+  // multifile (partial_sufsort.hpp:573-579): in HBM, or -- host tier -- in host memory, a chunk's words travelling with it
+  struct GtStore {
+    Dev d;
+    std::vector<uint32_t> h;
+    bool on_host = false;
+    void init(int64_t words, bool host) { on_host = host; if (host) h.assign((size_t)words, 0u); else d.alloc(4 * words, true); }
+    void zero() { if (on_host) std::fill(h.begin(), h.end(), 0u); else CK(psg_memset(d.p, 0, d.bytes)); }
+    uint32_t *dev() const { return on_host ? nullptr : d.as<uint32_t>(); }
+    // bits [dst_bit, dst_bit + nbits) = bits [0, nbits) of a device bit array
+    void put(int64_t dst_bit, const uint32_t *d_src, int64_t nbits) {
+      if (nbits <= 0) return;
+      if (!on_host) { CK(psg_bitcopy(d.as<uint32_t>(), dst_bit, d_src, 0, nbits)); return; }
+      std::vector<uint32_t> src((size_t)((nbits + 31) / 32 + 1), 0u);
+      CK(psg_d2h(src.data(), d_src, 4 * ((nbits + 31) / 32)));
+      if (nbits & 31) src[(size_t)((nbits - 1) >> 5)] &= (1u << (nbits & 31)) - 1u;
+      const int sh = (int)(dst_bit & 31);
+      const int64_t w0 = dst_bit >> 5, nw = (nbits + 31) / 32;
+      // (the destination bits are zero: the array is cleared for every block and every bit is written once)
+      for (int64_t k = 0; k < nw; ++k) {
+        const uint64_t v = (uint64_t)src[(size_t)k] << sh;
+        h[(size_t)(w0 + k)] |= (uint32_t)v;
+        if (sh) h[(size_t)(w0 + k + 1)] |= (uint32_t)(v >> 32);
+      }
+    }
+    void release() { d.release(); std::vector<uint32_t>().swap(h); }
+  } gt_cur, gt_new;
+  gt_cur.init(gt_words, host_tier); gt_new.init(gt_words, host_tier);
   std::vector<DoneHalfBlock> hbs;
   std::vector<uint32_t> cur_host;
   g_evict_resident = [&hbs]() { for (DoneHalfBlock &h : hbs) h.to_host(); };
@@ -461,17 +518,20 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
         hostbuf.resize((size_t)h.mbv.bytes);
         CK(psg_d2h(hostbuf.data(), h.mbv.p, h.mbv.bytes));
         write_file(ck_prefix + ".mbv." + std::to_string(h.beg), hostbuf.data(), hostbuf.size());
-      }
+      } else if (!h.mbv_host.empty()) write_file(ck_prefix + ".mbv." + std::to_string(h.beg), h.mbv_host.data(), 4 * h.mbv_host.size());
     }
-    hostbuf.resize((size_t)(4 * gt_words));
-    CK(psg_d2h(hostbuf.data(), gt_cur.p, 4 * gt_words));
-    write_file(ck_prefix + ".gt." + std::to_string(bid), hostbuf.data(), hostbuf.size());
+    if (gt_cur.on_host) write_file(ck_prefix + ".gt." + std::to_string(bid), gt_cur.h.data(), (size_t)(4 * gt_words));
+    else {
+      hostbuf.resize((size_t)(4 * gt_words));
+      CK(psg_d2h(hostbuf.data(), gt_cur.d.p, 4 * gt_words));
+      write_file(ck_prefix + ".gt." + std::to_string(bid), hostbuf.data(), hostbuf.size());
+    }
     const std::string mf = ck_prefix + ".manifest", tmp = mf + ".tmp";
     FILE *f = fopen(tmp.c_str(), "w");
     if (!f) throw std::runtime_error("cannot write " + tmp);
     fprintf(f, "psascan-mi355x-checkpoint 2\nn %ld block %ld ram %ld fp %lx\nnext_block %ld\nhalfblocks %zu\n", (long)n, (long)max_block_size, (long)ram_use,
             (unsigned long)text_fingerprint(), (long)(bid - 1), hbs.size());
-    for (const DoneHalfBlock &h : hbs) fprintf(f, "%ld %ld %d %ld\n", (long)h.beg, (long)h.size, (int)h.part_has_hi, (long)(h.mbv.p ? h.mbv.bytes : 0));
+    for (const DoneHalfBlock &h : hbs) fprintf(f, "%ld %ld %d %ld\n", (long)h.beg, (long)h.size, (int)h.part_has_hi, (long)(h.mbv.p ? h.mbv.bytes : (int64_t)(4 * h.mbv_host.size())));
     bool ok = fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = fclose(f) == 0 && ok;
     if (!ok || rename(tmp.c_str(), mf.c_str()) != 0) throw std::runtime_error("cannot write " + mf);
@@ -510,6 +570,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
           read_file(ck_prefix + ".mbv." + std::to_string(hb), buf.data(), buf.size());
           h.mbv.alloc(mv);
           CK(psg_h2d(h.mbv.p, buf.data(), mv));
+          h.mbv_bits = n - hb;
+          if (host_tier) h.spill_mbv();
         }
         struct stat sb;
         if (stat(h.part_file.c_str(), &sb) != 0 || sb.st_size != (off_t)((size_t)hs * (hh ? 5 : 4))) throw std::runtime_error("checkpoint part file missing or short: " + h.part_file);
@@ -519,7 +581,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       if (!ok) throw std::runtime_error("unreadable checkpoint manifest in " + opt.checkpoint_dir);
       std::vector<uint8_t> buf((size_t)(4 * gt_words));
       read_file(ck_prefix + ".gt." + std::to_string(next + 1), buf.data(), buf.size());
-      CK(psg_h2d(gt_cur.p, buf.data(), 4 * gt_words));
+      if (gt_cur.on_host) memcpy(gt_cur.h.data(), buf.data(), (size_t)(4 * gt_words)); else CK(psg_h2d(gt_cur.d.p, buf.data(), 4 * gt_words));
       first_bid = next;
       ck_saved = hbs.size();
       fprintf(stderr, "Resuming from the checkpoint in %s: %ld of %ld blocks done\n\n", opt.checkpoint_dir.c_str(), (long)(n_blocks - 1 - first_bid), (long)n_blocks);
@@ -540,9 +602,11 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   // uploaded (they live in host memory) and the pass is repeated with a search context -- the open starts are
   // found by string search over them (em_compute_initial_ranks.hpp:222-319), still in one kernel launch.
   struct PartRef { int64_t beg, size; const psa_host::PsaVec *lo; const psa_host::PsaHiVec *hi; DoneHalfBlock *owner; };   // (owner->psa_dev: already on the device)
+  Dev gt_chunk_in, gt_chunk_out;   // host tier: the gt words of the tail chunk being streamed
+  std::vector<uint32_t> gt_chunk_host;
   auto stream_pass = [&](psg_rank_t *rank, int64_t i0, int last_sym, int64_t tail_beg, int64_t T, const uint32_t *d_gt_in, int64_t rank_at_end,
                          uint32_t *d_gap, uint32_t *d_gt_out, int64_t cmp_end, const uint32_t *d_gt_cmp_end, const std::vector<PartRef> &parts,
-                         psg_stream_stats *st) {
+                         psg_stream_stats *st, GtStore *h_gt_in = nullptr, GtStore *h_gt_out = nullptr) {
     if (text_on_host) {
       // the tail in chunks, right to left; u = distance from the tail end (chunk bounds are multiples of 64, so the gt
       // words of a chunk start on a word boundary); every chunk starts from the rank the previous one ended with
@@ -567,9 +631,26 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
         psg_stream_args a{};
         a.rank = rank; a.block_i0 = i0; a.block_last_symbol = last_sym; a.d_tail = tail_buf[slot].as<uint8_t>(); a.tail_len = len; a.right_context = 0;
         a.d_gt_in = d_gt_in ? d_gt_in + (u_lo >> 5) : nullptr; a.rank_at_context_end = fin; a.d_gap = d_gap; a.d_gt_out = d_gt_out ? d_gt_out + (u_lo >> 5) : nullptr;
+        const int64_t cw = (len + 31) / 32;                    // gt words of this chunk (chunks start on word boundaries)
+        if (h_gt_in && h_gt_in->on_host) {                     // host tier: the chunk's gt words go up with it ...
+          if (gt_chunk_in.bytes < 4 * (C / 32 + 8)) gt_chunk_in.alloc(4 * (C / 32 + 8));
+          CK(psg_h2d(gt_chunk_in.p, h_gt_in->h.data() + (u_lo >> 5), 4 * (cw + 1)));
+          a.d_gt_in = gt_chunk_in.as<uint32_t>();
+        }
+        if (h_gt_out && h_gt_out->on_host) {
+          if (gt_chunk_out.bytes < 4 * (C / 32 + 8)) gt_chunk_out.alloc(4 * (C / 32 + 8));
+          CK(psg_memset(gt_chunk_out.p, 0, 4 * (cw + 4)));
+          a.d_gt_out = gt_chunk_out.as<uint32_t>();
+        }
         a.max_chains = max_chains; a.flags = u_lo == 0 ? PSG_GAP_UNINITIALIZED : 0; a.search = nullptr; a.tail_begin_abs = pos;
         psg_stream_stats s1{};
         if (psg_stream_gap_args(&a, &fin, &s1)) throw std::runtime_error(std::string("psg_stream_gap_args (tail chunk): ") + psg_last_error());
+        if (h_gt_out && h_gt_out->on_host) {                   // ... and the new ones come back
+          gt_chunk_host.resize((size_t)cw);
+          CK(psg_d2h(gt_chunk_host.data(), gt_chunk_out.p, 4 * cw));
+          if (len & 31) gt_chunk_host[(size_t)cw - 1] &= (1u << (len & 31)) - 1u;
+          for (int64_t w = 0; w < cw; ++w) h_gt_out->h[(size_t)((u_lo >> 5) + w)] |= gt_chunk_host[(size_t)w];
+        }
         acc.n_chains = std::max(acc.n_chains, s1.n_chains); acc.chain_len = s1.chain_len; acc.warmup_steps = std::max(acc.warmup_steps, s1.warmup_steps);
         acc.unresolved += s1.unresolved; acc.rounds += s1.rounds; acc.kernel_ms += s1.kernel_ms; acc.total_ms += s1.total_ms; acc.hist_ms += s1.hist_ms;
         if (T == 0) break;
@@ -739,25 +820,22 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       for (auto &t : w) if (t.joinable()) t.join();
     }
   } joiner{workers, pre_mu, pre_cv, stop_workers};
-  // the other staging buffers (page-locking 0.65 GiB takes ~0.1 s) on a helper thread, while the first leaves are being
-  // sorted and the text goes up
-  std::thread ring_thread;
-  struct RingJoin { std::thread &t; ~RingJoin() { if (t.joinable()) t.join(); } } ring_join{ring_thread};
-  if (use_batched)
-    ring_thread = std::thread([&]() {
-      for (int r = 1; r < RING && r < n_halves_sched; ++r) {
-        void *q = nullptr;
-        if (psg_host_alloc(&q, 2 * max_half + 64) != 0) return;   // (the run goes on with the buffers it has)
-        std::lock_guard<std::mutex> lk(pre_mu);
-        ring.p[r] = q; ring_ready = r + 1;
-        pre_cv.notify_all();
-      }
-    });
   if (!text_on_host && n) {
     const double tu = wclock();
     CK(psg_h2d(d_text.p, text.data(), n));                     // (the leaf sorters are running by now)
     if (g_verbose) fprintf(stderr, "Text on the device after %.2fs (upload %.2fs)\n\n", wclock() - start, wclock() - tu);
   }
+  // the other staging buffers (page-locking 0.65 GiB takes ~0.1 s), while the first leaves are being sorted.  (On this
+  // thread: a helper thread calling hipHostMalloc while this one copies through the library's staging buffers crashed
+  // inside the HIP runtime.)
+  if (use_batched)
+    for (int r = 1; r < RING && r < n_halves_sched; ++r) {
+      void *q = nullptr;
+      CK(psg_host_alloc(&q, 2 * max_half + 64));
+      std::lock_guard<std::mutex> lk(pre_mu);
+      ring.p[r] = q; ring_ready = r + 1;
+      pre_cv.notify_all();
+    }
   // the pre-sorted leaves of half `id`, left to right; empty when there are none (look-ahead off) or one gave up
   auto take_leaves = [&](int64_t id) -> std::vector<std::unique_ptr<HalfBlock>> {
     std::vector<std::unique_ptr<HalfBlock>> out;
@@ -1086,11 +1164,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t rs = bs - ls, mid = b + ls;
     fprintf(stderr, "Process block %ld/%ld [%ld..%ld):\n", (long)(n_blocks - bid), (long)n_blocks, (long)b, (long)e);
     if (g_verbose) fprintf(stderr, "    [%.2fs since start]\n", wclock() - start);
-    CK(psg_memset(gt_new.p, 0, gt_new.bytes));
+    gt_new.zero();
     bool have_cur_host = false;
     auto gt_tail_e = [&](int64_t v) {     // [text[e+v..) > text[e..)] from the previous block's passes (fetched when a sequential sort asks)
-      if (!have_cur_host) { cur_host.resize((size_t)gt_words); CK(psg_d2h(cur_host.data(), gt_cur.p, 4 * gt_words)); have_cur_host = true; }
       int64_t idx = n - (e + v);
+      if (gt_cur.on_host) return (bool)((gt_cur.h[(size_t)(idx >> 5)] >> (idx & 31)) & 1u);
+      if (!have_cur_host) { cur_host.resize((size_t)gt_words); CK(psg_d2h(cur_host.data(), gt_cur.d.p, 4 * gt_words)); have_cur_host = true; }
       return (bool)((cur_host[(size_t)(idx >> 5)] >> (idx & 31)) & 1u);
     };
     Half R, L;
@@ -1105,7 +1184,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (rs == 0) {
       DoneHalfBlock hbL = keep_half(L);
       if (opt.spill_psa) hbL.spill(opt.gap_prefix);
-      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, L.gt.as<uint32_t>(), 0, ls));
+      gt_new.put(n - mid, L.gt.as<uint32_t>(), ls);
       hbs.push_back(std::move(hbL));
       std::swap(gt_cur, gt_new);
       end_block(bid);
@@ -1132,7 +1211,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     DoneHalfBlock hbL = keep_half(L), hbR = keep_half(R);
     psg_stream_stats st;
     t0 = wclock();
-    stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
+    stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.dev(),
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}}, &st);
     log_phase("Stream (right half through left half, device)", t0, rs);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
@@ -1144,8 +1223,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     gapA.release();
     if (last_block) {  // :418-429 -- the left half's gap array is its merge bitvector
       hbL.mbv = std::move(bvA);
-      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
-      CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+      hbL.mbv_bits = bs;
+      if (host_tier) hbL.spill_mbv();
+      gt_new.put(n - e, gtA.as<uint32_t>(), rs);
+      gt_new.put(n - mid, d_lgt.as<uint32_t>(), ls);
       if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
       hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
       std::swap(gt_cur, gt_new);
@@ -1168,19 +1249,21 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     const int64_t T = n - e;
     Dev gapB(4 * psg_gap_words(bs), false);
     t0 = wclock();
-    stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.as<uint32_t>(), 0, gapB.as<uint32_t>(), gt_new.as<uint32_t>(), e, gt_cur.as<uint32_t>(),
-                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi, &hbR}}, &st);
+    stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.dev(), 0, gapB.as<uint32_t>(), gt_new.dev(), e, gt_cur.dev(),
+                {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi, &hbR}}, &st, &gt_cur, &gt_new);
     log_phase("Stream (tail through block, device)", t0, T);
     if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
     rankBg.reset();
-    CK(psg_bitcopy(gt_new.as<uint32_t>(), n - e, gtA.as<uint32_t>(), 0, rs));
-    CK(psg_bitcopy(gt_new.as<uint32_t>(), n - mid, d_lgt.as<uint32_t>(), 0, ls));
+    gt_new.put(n - e, gtA.as<uint32_t>(), rs);
+    gt_new.put(n - mid, d_lgt.as<uint32_t>(), ls);
     // ---- split (:536-542)
     t0 = wclock();
     hbL.mbv.alloc(4 * ((bs + T + 31) / 32 + 2));
     hbR.mbv.alloc(4 * ((rs + T + 31) / 32 + 2));
     CK(psg_split_gap(gapB.as<uint32_t>(), bvA.as<uint32_t>(), ls, rs, T, hbL.mbv.as<uint32_t>(), hbR.mbv.as<uint32_t>()));
     log_phase("Compute gaps of half-blocks (device)", t0, bs);
+    hbL.mbv_bits = bs + T; hbR.mbv_bits = rs + T;
+    if (host_tier) { const double ts = wclock(); hbL.spill_mbv(); hbR.spill_mbv(); if (g_verbose) fprintf(stderr, "    merge bitvectors to host memory: %.2fs\n", wclock() - ts); }
     if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
@@ -1209,19 +1292,49 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     hbs[h].settle();
     hbs[h].map_back();
     desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr,
-                               hbs[h].psa_dev.as<uint32_t>(), hbs[h].psa_hi_dev.as<uint8_t>()};
+                               hbs[h].psa_dev.as<uint32_t>(), hbs[h].psa_hi_dev.as<uint8_t>(),
+                               h + 1 < hbs.size() && !hbs[h].mbv_host.empty() ? hbs[h].mbv_host.data() : nullptr,
+                               h + 1 < hbs.size() && !hbs[h].mbv_samp.empty() ? hbs[h].mbv_samp.data() : nullptr};
   }
-  struct SinkCtx { FILE *out; bool ok; int64_t entries; } sctx{out, true, 0};
+  // --check with the text in host memory: the same property check on the host (sum of all entries, sampled adjacent
+  // pairs compared in the memory-mapped text), slice by slice as the output arrives
+  struct HostCheck {
+    const uint8_t *text; int64_t n, samples; bool on;
+    uint64_t sum = 0, rng = 88172645463325252ull; int64_t bad = 0, undecided = 0;
+    static int64_t entry(const uint8_t *p) { return (int64_t)p[0] | (int64_t)p[1] << 8 | (int64_t)p[2] << 16 | (int64_t)p[3] << 24 | (int64_t)p[4] << 32; }
+    void slice(const uint8_t *sa5, int64_t cnt) {
+      const int nt = 8;
+      uint64_t part[nt] = {0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { uint64_t a = 0; for (int64_t k = cnt * t / nt; k < cnt * (t + 1) / nt; ++k) a += (uint64_t)entry(sa5 + 5 * k); part[t] = a; });
+      for (auto &x : th) x.join();
+      for (int t = 0; t < nt; ++t) sum += part[t];
+      for (int64_t q = 0; q < samples && cnt > 1; ++q) {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        const int64_t k = (int64_t)(rng % (uint64_t)(cnt - 1)), a = entry(sa5 + 5 * k), b = entry(sa5 + 5 * (k + 1));
+        if (a < 0 || a >= n || b < 0 || b >= n || a == b) { ++bad; continue; }
+        int64_t l = 0;
+        const int64_t cap = (int64_t)1 << 22;
+        while (l < cap && a + l < n && b + l < n && text[a + l] == text[b + l]) ++l;
+        if (l >= cap) { ++undecided; continue; }
+        const bool less = a + l >= n ? true : (b + l >= n ? false : text[a + l] < text[b + l]);
+        if (!less) ++bad;
+      }
+    }
+  } hcheck{text.data(), n, opt.check_samples, opt.check_samples >= 0 && text_on_host};
+  struct SinkCtx { FILE *out; bool ok; int64_t entries; HostCheck *hc; } sctx{out, true, 0, &hcheck};
   psg_sink_fn sink = [](void *c, const uint8_t *h_sa5, int64_t, int64_t cnt) -> int {
     SinkCtx *x = (SinkCtx *)c;
     x->entries += cnt;
+    if (x->hc->on) x->hc->slice(h_sa5, cnt);
     if (x->out && fwrite(h_sa5, 1, (size_t)(5 * cnt), x->out) != (size_t)(5 * cnt)) { x->ok = false; return 1; }
     return 0;
   };
   psg_merge_check chk{d_text.as<uint8_t>(), n, opt.check_samples, 12345, 0, 0};
   psg_merge_stream_stats ms;
   const int64_t slice = 64LL << 20;  // output entries per slice
-  int mrc = psg_merge_stream(desc.data(), (int)desc.size(), std::min(slice, n), opt.check_samples >= 0 ? &chk : nullptr, sink, &sctx, &ms);
+  int mrc = psg_merge_stream(desc.data(), (int)desc.size(), std::min(slice, n), opt.check_samples >= 0 && !hcheck.on ? &chk : nullptr, sink, &sctx, &ms);
+  if (hcheck.on) { chk.sum = hcheck.sum; chk.bad_pairs = hcheck.bad; }
   if (!sctx.ok) throw std::runtime_error("write failed on " + out_fn);
   if (mrc) throw std::runtime_error(std::string("psg_merge_stream: ") + psg_last_error());
   if (sctx.entries != n) throw std::runtime_error("merge produced a wrong number of entries");
@@ -1236,7 +1349,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   if (opt.check_samples >= 0) {
     const unsigned __int128 nn = (unsigned __int128)n * (unsigned __int128)(n - 1) / 2;
     const bool sum_ok = chk.sum == (uint64_t)nn;
-    fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples));
+    fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order%s\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples),
+            hcheck.on ? (hcheck.undecided ? " (on the host; some pairs undecided within 4 Mi symbols)" : " (on the host)") : "");
     if (!sum_ok || chk.bad_pairs) throw std::runtime_error("output check failed");
   }
   checkpoint_clear();
@@ -1265,7 +1379,7 @@ int main(int argc, char **argv) {
                                          {"fanout", required_argument, NULL, 1006}, {"no-device-merge", no_argument, NULL, 1007},
                                          {"device-sort", no_argument, NULL, 1008}, {"text-on-host", no_argument, NULL, 1009},
                                          {"tail-chunk", required_argument, NULL, 1010}, {"checkpoint", required_argument, NULL, 1011},
-                                         {"stop-after", required_argument, NULL, 1012}, {NULL, 0, NULL, 0}};
+                                         {"stop-after", required_argument, NULL, 1012}, {"hbm-limit", required_argument, NULL, 1013}, {NULL, 0, NULL, 0}};
   uint64_t ram_use = (uint64_t)3584 << 20;
   std::string output_filename, gap_filename;
   Options opt;
@@ -1292,6 +1406,7 @@ int main(int argc, char **argv) {
       case 1009: opt.text_on_host = true; break;
       case 1011: opt.checkpoint_dir = optarg; break;
       case 1012: opt.stop_after = atoll(optarg); break;
+      case 1013: { uint64_t v; if (!parse_number(optarg, &v) || v < ((uint64_t)64 << 20)) { fprintf(stderr, "Error: bad --hbm-limit\n\n"); usage(EXIT_FAILURE); } opt.hbm_limit = (int64_t)v; break; }
       case 1010: { uint64_t v; if (!parse_number(optarg, &v) || v < 64) { fprintf(stderr, "Error: bad --tail-chunk\n\n"); usage(EXIT_FAILURE); } opt.tail_chunk = (int64_t)v; break; }
       default: usage(EXIT_FAILURE); break;
     }

@@ -69,6 +69,11 @@ int psg_copy_wait(psg_copy_t *copy);
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved);
 /* the device's memory as the driver sees it (hipMemGetInfo) */
 int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes);
+/* a budget below the device's memory: psg_malloc and every internal allocation fail with PSG_ENOMEM once more than
+ * `bytes` would be handed out (0 = no budget); psg_device_memory then reports the budget.  The reference runs under a
+ * RAM budget the same way (-m, psascan.hpp:73-91); construct_sa --hbm-limit uses this to run its spill paths (partial
+ * SAs, merge bitvectors and gt bits in host memory, the text uploaded chunk by chunk) on a device that would hold all. */
+int psg_set_memory_limit(int64_t bytes);
 /* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int psg_set_stream(void *hip_stream);
 
@@ -309,7 +314,18 @@ typedef struct {
   const uint32_t *d_mbv;     /* device; size + (sizes of all later half-blocks) bits; NULL for the last */
   const uint32_t *d_psa_lo;  /* optional: this half-block's partial SA is ALREADY in HBM (h_psa_* are then ignored): */
   const uint8_t *d_psa_hi;   /* a caller with HBM to spare keeps some of them resident and saves their PCIe transfer */
+  /* optional: the merge bitvector is in HOST memory (d_mbv NULL; all or none of the half-blocks) -- the reference keeps
+   * its gap arrays in files and streams them through the merge (merge.hpp:80,145; gap_array.hpp:156-182).  h_mbv: the
+   * words as psg_mbv_spill wrote them, h_mbv_samp: its rank samples.  Every output slice then uploads the words of
+   * every level it touches (128-word aligned pieces) next to the pieces of the partial SAs.                       */
+  const uint32_t *h_mbv;
+  const uint64_t *h_mbv_samp;
 } psg_hb_host_desc;
+/* copy a finished merge bitvector of nbits bits out of HBM: h_words receives (nbits + 31) / 32 words (+ up to 3 of
+ * padding: room for psg_mbv_spill_words(nbits) words), h_samp the number of one bits in front of every group of 4096
+ * bits ((nbits + 4095) / 4096 + 1 values, the last one = all ones).  Both may be pageable memory.                  */
+int64_t psg_mbv_spill_words(int64_t nbits);
+int psg_mbv_spill(const uint32_t *d_mbv, int64_t nbits, uint32_t *h_words, uint64_t *h_samp);
 typedef int (*psg_sink_fn)(void *ctx, const uint8_t *h_sa5, int64_t first_entry, int64_t n_entries);
 typedef struct {
   const uint8_t *d_text;     /* the whole text on the device */

@@ -23,7 +23,7 @@ class HbDescC(C.Structure):
 
 class HbHostDescC(C.Structure):
     _fields_ = [("beg", C.c_int64), ("size", C.c_int64), ("h_psa_lo", C.c_void_p), ("h_psa_hi", C.c_void_p), ("d_mbv", C.c_void_p),
-                ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p)]
+                ("d_psa_lo", C.c_void_p), ("d_psa_hi", C.c_void_p), ("h_mbv", C.c_void_p), ("h_mbv_samp", C.c_void_p)]
 
 
 class MergeCheckC(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "psg_mem_stats": (_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "psg_device_memory": (_int, [C.POINTER(_i64), C.POINTER(_i64)]),
     "psg_set_stream": (_int, [_vp]),
+    "psg_set_memory_limit": (_int, [_i64]),
     "psg_gap_words": (_i64, [_i64]),
     "psg_gap_values": (_int, [_vp, _i64, _vp]),
     "psg_rank_build": (_int, [_vp, _i64, _int, C.POINTER(_vp)]),
@@ -122,6 +123,8 @@ SIGNATURES = {
     "psg_merge_plan_create_sliced": (_int, [C.POINTER(HbSliceDescC), _int, C.POINTER(_vp)]),
     "psg_merge_stream": (_int, [C.POINTER(HbHostDescC), _int, _i64, C.POINTER(MergeCheckC), SINK_FN, _vp, C.POINTER(MergeStreamStatsC)]),
     "psg_merge_leaves": (_int, [C.POINTER(SearchCtxC), _i64, _i64, C.POINTER(_i64), _i64, _vp, _int, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(LeafMergeStatsC)]),
+    "psg_mbv_spill_words": (_i64, [_i64]),
+    "psg_mbv_spill": (_int, [_vp, _i64, _vp, _vp]),
     "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
     "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "psg_last_kernel_ms": (C.c_double, []),

@@ -435,6 +435,11 @@ def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, sa
     for k, hb in enumerate(half_blocks):
         arr[k].beg, arr[k].size = hb["beg"], hb["size"]
         arr[k].d_mbv = _ptr(hb.get("mbv"))
+        if hb.get("mbv_host") is not None:                  # merge bitvector spilled to host memory (mbv_spill)
+            words, samp = hb["mbv_host"]
+            keep += [words, samp]
+            arr[k].d_mbv = None
+            arr[k].h_mbv, arr[k].h_mbv_samp = words.ctypes.data, samp.ctypes.data
         if isinstance(hb["psa_lo"], DeviceBuffer):          # resident in HBM: used where it lies
             arr[k].d_psa_lo = hb["psa_lo"].ptr
             arr[k].d_psa_hi = _ptr(hb.get("psa_hi"))
@@ -468,6 +473,14 @@ def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, sa
         raise err[0]
     check(rc)
     return st, ((chk.sum, chk.bad_pairs) if chk is not None else None)
+
+
+def mbv_spill(d_mbv, nbits):
+    """psg_mbv_spill: a merge bitvector leaves HBM -> (words: np.uint32, rank samples: np.uint64) in host memory"""
+    words = np.zeros(lib().psg_mbv_spill_words(nbits), np.uint32)
+    samp = np.zeros((nbits + 4095) // 4096 + 1, np.uint64)
+    check(lib().psg_mbv_spill(_ptr(d_mbv), nbits, words.ctypes.data, samp.ctypes.data))
+    return words, samp
 
 
 def bitcopy(d_dst, dst_bit, d_src, src_bit, nbits):

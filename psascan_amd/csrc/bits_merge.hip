@@ -809,12 +809,13 @@ extern "C" void psg_merge_plan_free(psg_merge_plan_t *p) {
 }
 
 // need_psa = false: the partial SAs are not on the device (psg_merge_stream); lo/hi of the levels stay null
-static int plan_build(const psg_hb_desc *hbs, int H, bool need_psa, psg_merge_plan_t **out) {
+// need_mbv = false: neither are the merge bitvectors (they come slice by slice from host memory): mbv/samp stay null
+static int plan_build(const psg_hb_desc *hbs, int H, bool need_psa, psg_merge_plan_t **out, bool need_mbv = true) {
   psg_merge_plan *p = new psg_merge_plan();
   p->H = H;
   std::vector<i64> nh(H + 1, 0);
   for (int h = H - 1; h >= 0; --h) {
-    if (hbs[h].size < 1 || (need_psa && !hbs[h].d_psa_lo) || (h + 1 < H && !hbs[h].d_mbv) || (h > 0 && hbs[h].beg < hbs[h - 1].beg)) {
+    if (hbs[h].size < 1 || (need_psa && !hbs[h].d_psa_lo) || (need_mbv && h + 1 < H && !hbs[h].d_mbv) || (h > 0 && hbs[h].beg < hbs[h - 1].beg)) {
       psg_merge_plan_free(p); set_error("psg_merge_plan_create: bad half-block descriptor " + std::to_string(h)); return PSG_EINVAL;
     }
     nh[h] = nh[h + 1] + hbs[h].size;
@@ -824,7 +825,8 @@ static int plan_build(const psg_hb_desc *hbs, int H, bool need_psa, psg_merge_pl
   for (int h = 0; h < H; ++h) {
     MergeLevel L{};
     L.lo = hbs[h].d_psa_lo; L.hi = hbs[h].d_psa_hi; L.beg = hbs[h].beg; L.size = hbs[h].size;
-    if (h + 1 < H) {
+    if (h + 1 < H && !need_mbv) { L.mbv = nullptr; L.nbits = nh[h]; L.samp = nullptr; }
+    else if (h + 1 < H) {
       L.mbv = hbs[h].d_mbv; L.nbits = nh[h];
       i64 ntiles = cdiv(L.nbits, TILE_B);
       void *samp = nullptr; DevBuf tot;
@@ -1061,6 +1063,36 @@ static void parallel_memcpy(const std::vector<CopyPiece> &pieces) {
   for (auto &t : th) t.join();
 }
 
+// ---- a merge bitvector leaves HBM (construct_sa --hbm-limit; the reference writes its gap arrays to files,
+// gap_array.hpp:156-182, and reads them back during the merge, merge.hpp:80,145)
+extern "C" int64_t psg_mbv_spill_words(int64_t nbits) { return ((nbits + 31) / 32 + 3) / 4 * 4; }
+extern "C" int psg_mbv_spill(const uint32_t *d_mbv, int64_t nbits, uint32_t *h_words, uint64_t *h_samp) {
+  PSG_REQUIRE(d_mbv && nbits >= 1 && h_words && h_samp, "psg_mbv_spill");
+  const i64 ntiles = cdiv(nbits, TILE_B), nwords = (nbits + 31) / 32;
+  DevBuf samp;
+  int rc;
+  if ((rc = samp.alloc((ntiles + 1) * 8))) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), d_mbv, nbits, samp.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(samp.as<u64>(), ntiles, samp.as<u64>() + ntiles))) return rc;   // the total lands behind the last sample
+  if ((rc = psg::copy_d2h(h_samp, samp.p, (size_t)(ntiles + 1) * 8))) return rc;
+  if ((rc = psg::copy_d2h(h_words, d_mbv, (size_t)nwords * 4))) return rc;
+  for (i64 w = nwords; w < psg_mbv_spill_words(nbits); ++w) h_words[w] = 0;
+  if (nbits & 31) h_words[nwords - 1] &= (1u << (nbits & 31)) - 1u;
+  return 0;
+}
+
+// number of one bits in front of bit q of a merge bitvector in host memory (samples per 4096 bits + popcount)
+static i64 host_rank1(const u32 *words, const u64 *samp, i64 nbits, i64 q) {
+  const i64 ntiles = cdiv(nbits, TILE_B);
+  if (q >= nbits) return (i64)samp[ntiles];
+  const i64 g = q >> 12;
+  i64 ones = (i64)samp[g];
+  for (i64 w = g << 7; w < (q >> 5); ++w) ones += __builtin_popcount(words[w]);
+  if (q & 31) ones += __builtin_popcount(words[q >> 5] & ((1u << (q & 31)) - 1u));
+  return ones;
+}
+
 extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slice_entries, psg_merge_check *check,
                                 psg_sink_fn sink, void *sink_ctx, psg_merge_stream_stats *stats) {
   PSG_REQUIRE(hbs && H >= 1 && slice_entries >= 1, "psg_merge_stream");
@@ -1074,29 +1106,64 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
     dd[(size_t)h] = psg_hb_desc{hbs[h].beg, hbs[h].size, nullptr, nullptr, hbs[h].d_mbv};
     any_hi |= hbs[h].d_psa_lo ? hbs[h].d_psa_hi != nullptr : hbs[h].h_psa_hi != nullptr;
   }
+  // merge bitvectors in host memory (all of them or none): every slice brings the words it needs along
+  bool host_mbv = false;
+  for (int h = 0; h + 1 < H; ++h) host_mbv |= !hbs[h].d_mbv && hbs[h].h_mbv;
+  if (host_mbv)
+    for (int h = 0; h + 1 < H; ++h) PSG_REQUIRE(!hbs[h].d_mbv && hbs[h].h_mbv && hbs[h].h_mbv_samp, "psg_merge_stream: merge bitvectors in host memory: all of them, with their rank samples");
   psg_merge_plan *plan = nullptr;
-  if (int rc = plan_build(dd.data(), H, false, &plan)) return rc;
+  if (int rc = plan_build(dd.data(), H, false, &plan, !host_mbv)) return rc;
   struct PlanGuard { psg_merge_plan *p; ~PlanGuard() { psg_merge_plan_free(p); } } plan_guard{plan};
+  if (host_mbv && slice_entries > ((i64)16 << 20)) slice_entries = (i64)16 << 20;   // a slice carries up to H levels of bits: smaller slices bound the staging
   const i64 n = plan->n, ns = cdiv(n, slice_entries);
   psg_merge_stream_stats st = {};
   st.slices = ns;
   // ---- cursors of every half-block at every slice boundary
   std::vector<i64> xs((size_t)ns + 1);
   for (i64 k = 0; k <= ns; ++k) xs[(size_t)k] = std::min<i64>(n, k * slice_entries);
-  DevBuf xs_d, cur_d;
   int rc;
-  if ((rc = xs_d.alloc((ns + 1) * 8)) || (rc = cur_d.alloc((ns + 1) * H * 8))) return rc;
-  if ((rc = psg::copy_h2d(xs_d.p, xs.data(), (size_t)(ns + 1) * 8))) return rc;
-  hipLaunchKernelGGL(merge_cursor_kernel, dim3((unsigned)(ns + 1)), dim3(128), 0, stream(), plan->d_levels, H, xs_d.as<i64>(), cur_d.as<i64>());
-  PSG_HIP(hipGetLastError());
-  std::vector<i64> cur((size_t)(ns + 1) * H);
-  if ((rc = psg::copy_d2h(cur.data(), cur_d.p, cur.size() * 8))) return rc;
+  std::vector<i64> cur((size_t)(ns + 1) * H), qpos;      // qpos[b * H + h]: where the walk of boundary b stands in level h's bitvector
+  if (host_mbv) {
+    qpos.resize((size_t)(ns + 1) * H);
+    for (i64 b = 0; b <= ns; ++b) {
+      i64 q = xs[(size_t)b];
+      for (int h = 0; h < H; ++h) {
+        qpos[(size_t)b * H + h] = q;
+        if (h == H - 1) { cur[(size_t)b * H + h] = q; break; }
+        const i64 ones = host_rank1(hbs[h].h_mbv, hbs[h].h_mbv_samp, plan->levels[(size_t)h].nbits, q);
+        cur[(size_t)b * H + h] = q - ones;
+        q = ones;
+      }
+    }
+  } else {
+    DevBuf xs_d, cur_d;
+    if ((rc = xs_d.alloc((ns + 1) * 8)) || (rc = cur_d.alloc((ns + 1) * H * 8))) return rc;
+    if ((rc = psg::copy_h2d(xs_d.p, xs.data(), (size_t)(ns + 1) * 8))) return rc;
+    hipLaunchKernelGGL(merge_cursor_kernel, dim3((unsigned)(ns + 1)), dim3(128), 0, stream(), plan->d_levels, H, xs_d.as<i64>(), cur_d.as<i64>());
+    PSG_HIP(hipGetLastError());
+    if ((rc = psg::copy_d2h(cur.data(), cur_d.p, cur.size() * 8))) return rc;
+  }
   for (int h = 0; h < H; ++h)
     if (cur[(size_t)ns * H + h] != hbs[h].size || cur[(size_t)h] != 0) { set_error("psg_merge_stream: cursor check failed at half-block " + std::to_string(h)); return PSG_ECHECK; }
   // ---- buffers: two slots each
   const i64 lo_cap = slice_entries * 4 + (i64)H * 16, hi_cap = any_hi ? slice_entries + (i64)H * 16 : 0, in_cap = lo_cap + hi_cap;
   const i64 out_cap = 5 * slice_entries + 16;
-  DevBuf din[2], dout[2], dlv[2], acc;
+  // host-resident merge bitvectors: per slice and level the words [w0, w1) (whole groups of 128 words) + their samples
+  auto mbv_piece = [&](i64 k, int h, i64 &w0, i64 &w1) {
+    const i64 nw = cdiv(cdiv(plan->levels[(size_t)h].nbits, 32), 128) * 128;
+    w0 = (qpos[(size_t)k * H + h] >> 5) / 128 * 128;
+    w1 = std::min(nw, ((qpos[(size_t)(k + 1) * H + h] + 31) >> 5) / 128 * 128 + 256);
+    if (w1 < w0) w1 = w0;
+  };
+  i64 mbv_cap = 0;                                   // bytes of staging a slice needs for bitvector words + samples
+  if (host_mbv)
+    for (i64 k = 0; k < ns; ++k) {
+      i64 need = 0;
+      for (int h = 0; h + 1 < H; ++h) { i64 w0, w1; mbv_piece(k, h, w0, w1); need += (w1 - w0) * 4 + ((w1 - w0) / 128 + 2) * 8; }
+      mbv_cap = std::max(mbv_cap, need + 64);
+    }
+  DevBuf din[2], dout[2], dlv[2], dmbv[2], acc;
+  char *pin_mbv[2] = {nullptr, nullptr};
   char *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
   MergeLevel *pin_lv[2] = {nullptr, nullptr};
   const bool direct = [&] {
@@ -1109,6 +1176,10 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
     if (!direct) pin_in[s] = (char *)pinned_buf(8 + s, (size_t)in_cap);
     if (sink) pin_out[s] = (char *)pinned_buf(10 + s, (size_t)out_cap);
     if ((!direct && !pin_in[s]) || (sink && !pin_out[s])) { set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
+    if (host_mbv) {
+      if ((rc = dmbv[s].alloc(mbv_cap))) return rc;
+      if (hipHostMalloc((void **)&pin_mbv[s], (size_t)mbv_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
+    }
   }
   pin_lv[0] = (MergeLevel *)pinned_buf(12, 2 * sizeof(MergeLevel) * (size_t)H);
   if (!pin_lv[0]) { set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
@@ -1119,6 +1190,7 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   hipEvent_t ev_up[2] = {event_acquire(), event_acquire()}, ev_dn[2] = {event_acquire(), event_acquire()};
   hipEvent_t ev_k0[2] = {event_acquire(), event_acquire()}, ev_k1[2] = {event_acquire(), event_acquire()};
   struct EvGuard { hipEvent_t *a, *b, *c, *d; ~EvGuard() { for (int s = 0; s < 2; ++s) { event_release(a[s]); event_release(b[s]); event_release(c[s]); event_release(d[s]); } } } ev_guard{ev_up, ev_dn, ev_k0, ev_k1};
+  struct PinMbvGuard { char **p; ~PinMbvGuard() { for (int s = 0; s < 2; ++s) if (p[s]) (void)hipHostFree(p[s]); } } pin_mbv_guard{pin_mbv};
   PSG_HIP(psg::sync_stream());   // cursor work and the memset are done before the copy stream starts
   auto wait_event = [](hipEvent_t e) { hipError_t q; while ((q = hipEventQuery(e)) == hipErrorNotReady) { } return q; };
   int result = 0;
@@ -1181,6 +1253,28 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
         offh += (len + 15) / 16 * 16;
       }
       pin_lv[s][h] = L;
+    }
+    if (host_mbv) {   // the words of every level this slice touches + the rank samples of their groups
+      i64 moff = 0;
+      for (int h = 0; h + 1 < H; ++h) {
+        i64 w0, w1;
+        mbv_piece(k, h, w0, w1);
+        const i64 nwords_real = psg_mbv_spill_words(plan->levels[(size_t)h].nbits);
+        const i64 wcopy = std::max<i64>(0, std::min(w1, nwords_real) - w0);
+        pieces.push_back({pin_mbv[s] + moff, (const char *)(hbs[h].h_mbv + w0), (size_t)wcopy * 4});
+        if (w1 - w0 > wcopy) memset(pin_mbv[s] + moff + wcopy * 4, 0, (size_t)(w1 - w0 - wcopy) * 4);
+        pin_lv[s][h].mbv = (const u32 *)(dmbv[s].as<char>() + moff) - w0;
+        moff += (w1 - w0) * 4;
+        const i64 g0 = w0 / 128, ng = (w1 - w0) / 128 + 1, ntiles = cdiv(plan->levels[(size_t)h].nbits, TILE_B);
+        u64 *sd = (u64 *)(pin_mbv[s] + moff);
+        for (i64 g = 0; g < ng; ++g) sd[g] = hbs[h].h_mbv_samp[std::min(g0 + g, ntiles)];
+        pin_lv[s][h].samp = (const u64 *)(dmbv[s].as<char>() + moff) - g0;
+        moff += (ng + 1) * 8;
+        st.h2d_bytes += (w1 - w0) * 4;
+      }
+      parallel_memcpy(pieces);                      // (with pageable partial SAs their pieces are in the same list)
+      pieces.clear();
+      PSG_HIP(hipMemcpyAsync(dmbv[s].p, pin_mbv[s], (size_t)moff, hipMemcpyHostToDevice, up));
     }
     if (!direct) {
       parallel_memcpy(pieces);

@@ -47,6 +47,7 @@ hipError_t pool_alloc(void **p, size_t bytes);
 void pool_free(void *p);
 void pool_trim();
 size_t pool_cached_bytes();   // bytes held in the cache (reusable without asking the driver)
+size_t mem_available();       // what a new structure may take: the rest of the budget (psg_set_memory_limit) or free + cached device memory
 
 // grow-only pinned host buffers (slot 0..15): 0-3 stream pass (per-chain arrays, read-backs), 4 wide-log slab
 // bounds, 7 copy staging, 8-11 streamed merge (PSA pieces in, .sa5 slices out), 12 merge cursors, 13 the LDS tables of a pass; 5-6 search positions / ranks

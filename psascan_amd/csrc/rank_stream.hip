@@ -856,12 +856,10 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
     const char *env = getenv("PSG_RANK_LAYOUT");
     bool want_sm = data_bytes == 1 || (data_bytes == 0 && !(env && !strcmp(env, "block")));
     if (want_sm) {
-      size_t free_b = 0, total_b = 0;
-      (void)hipMemGetInfo(&free_b, &total_b);
       bool fell_back = true, l8_failed = false;
-      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), true, &fell_back, &l8_failed);
+      int rc = sm_build(r, d_bwt, m, h, 0.35 * (double)mem_available(), true, &fell_back, &l8_failed);
       if (!rc && fell_back && l8_failed) {   // a BWT with runs overflows the 4 inline positions: 16-byte entries (one failed fill ~ 10 ms)
-        rc = sm_build(r, d_bwt, m, h, 0.35 * (double)(free_b + pool_cached_bytes()), false, &fell_back, &l8_failed);
+        rc = sm_build(r, d_bwt, m, h, 0.35 * (double)mem_available(), false, &fell_back, &l8_failed);
       }
       if (rc) { delete r; return rc; }
       if (!fell_back) {
@@ -881,9 +879,7 @@ extern "C" int psg_rank_build(const uint8_t *d_bwt, int64_t m, int data_bytes, p
       // general alphabet: the smaller the block, the fewer load instructions per query
       // (B=32: counter dword + ONE dwordx4; B=64: + two; ...) at 33 / 17 / 9 / 5 bytes per symbol.
       // Take the smallest block whose structure stays within a quarter of the free HBM.
-      size_t free_b = 0, total_b = 0;
-      (void)hipMemGetInfo(&free_b, &total_b);
-      double budget = 0.35 * (double)(free_b + pool_cached_bytes());
+      double budget = 0.35 * (double)mem_available();
       r->cnt = 256;
       r->B = 33.0 * m <= budget ? 32 : 17.0 * m <= budget ? 64 : 9.0 * m <= budget ? 128 : 256;
     }

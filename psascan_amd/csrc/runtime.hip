@@ -50,6 +50,7 @@ static const size_t BIG = (size_t)1 << 20, GRAN = (size_t)2 << 20, SEG_MAX = (si
 
 static size_t pool_round(size_t b) { return (b + 4095) / 4096 * 4096; }
 static size_t g_in_use = 0, g_peak = 0, g_small_reserved = 0;   // guarded by g_pool_mu
+static size_t g_limit = 0;      // psg_set_memory_limit: the library hands out at most this many bytes (0 = what the device has)
 static void note_use(size_t add) { g_in_use += add; if (g_in_use > g_peak) g_peak = g_in_use; }
 
 static void *arena_carve(size_t need) {   // best fit over all segments; g_pool_mu held
@@ -84,6 +85,10 @@ static void arena_release_empty() {   // give wholly free segments back to the d
 }
 
 hipError_t pool_alloc(void **p, size_t bytes) {
+  if (g_limit) {   // a budget below the device's memory (construct_sa --hbm-limit): the spill paths run on any device
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_in_use + bytes > g_limit) { *p = nullptr; return hipErrorOutOfMemory; }
+  }
   if (bytes >= BIG) {
     const size_t need = (bytes + GRAN - 1) / GRAN * GRAN;
     size_t total = 0;
@@ -158,6 +163,17 @@ void pool_free(void *p) {
   g_pool_free.emplace(it->second, p);
   g_in_use -= it->second;
   g_pool_live.erase(it);
+}
+
+size_t pool_cached_bytes();
+// bytes a new structure may still take: under a budget what is left of it, otherwise what the driver and the cache have
+size_t mem_available() {
+  size_t lim, used;
+  { std::lock_guard<std::mutex> lk(g_pool_mu); lim = g_limit; used = g_in_use; }
+  if (lim) return lim > used ? lim - used : 0;
+  size_t f = 0, t = 0;
+  (void)hipMemGetInfo(&f, &t);
+  return f + pool_cached_bytes();
 }
 
 size_t pool_cached_bytes() {
@@ -608,9 +624,19 @@ int psg_copy_wait(psg_copy_t *c) {
   return rc;
 }
 
+int psg_set_memory_limit(int64_t bytes) {
+  PSG_REQUIRE(bytes >= 0, "psg_set_memory_limit");
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_limit = (size_t)bytes;
+  return 0;
+}
 int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
   size_t f = 0, t = 0;
   PSG_HIP(hipMemGetInfo(&f, &t));
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_limit) { t = std::min(t, g_limit); f = std::min(f, g_limit > g_in_use ? g_limit - g_in_use : 0); }
+  }
   if (free_bytes) *free_bytes = (int64_t)f;
   if (total_bytes) *total_bytes = (int64_t)t;
   return 0;

@@ -984,6 +984,23 @@ def test_merge_stream_vs_oracle(A, cuts, pinned):
     # output dropped on the device (bench mode): only the check comes back
     st2, chk2 = A.merge_stream(hbs, 4096, None, check_text=d_text, n=n, samples_per_slice=512, seed=4)
     assert chk2 == chk and st2.d2h_bytes == 0
+    # merge bitvectors spilled to host memory (psg_mbv_spill; the reference reads its gap files back during the merge,
+    # merge.hpp:80,145): every slice uploads the words of every level it touches -- same bytes
+    nh = [sum(sizes[k:]) for k in range(len(sizes))]
+    spilled = []
+    for k, hb in enumerate(hbs):
+        hb2 = dict(hb)
+        if hb["mbv"] is not None:
+            words, samp = A.mbv_spill(hb["mbv"], nh[k])
+            assert int(samp[-1]) == nh[k] - sizes[k] and samp[0] == 0
+            hb2["mbv"], hb2["mbv_host"] = None, (words, samp)
+        spilled.append(hb2)
+    got3 = np.zeros(5 * n, np.uint8)
+
+    def sink3(view, first, cnt):
+        got3[5 * first: 5 * (first + cnt)] = view
+    st3, chk3 = A.merge_stream(spilled, 2048, sink3, check_text=d_text, n=n, samples_per_slice=512, seed=3)
+    assert np.array_equal(got3, want) and chk3 == chk and (st3.h2d_bytes > 4 * n or len(cuts) == 2)
 
 
 def test_merge_stream_high_byte(A):

@@ -476,7 +476,50 @@ def test_cli_text_on_host_chunked_tails(tmp_path, kind):
     assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
     r = subprocess.run([CLI, "-m", "1G", "--text-on-host", "--check", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="4"))
-    assert r.returncode == 1 and "--check needs the text in HBM" in r.stderr
+    assert r.returncode == 0 and "check: permutation sum ok, 0 of" in r.stderr and "(on the host)" in r.stderr, r.stderr[-2000:]   # the check runs on the host then
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rand", "sig3", "english", "per3"])
+def test_cli_hbm_limit_host_tier(tmp_path, kind):
+    """--hbm-limit: the external-memory schedule with HBM in the place of the reference's RAM budget.  The text, the gt bits
+    (a chunk's words travel with the chunk), the partial SAs and every finished merge bitvector (psg_mbv_spill) live in
+    host memory; the merge streams all of them back slice by slice.  Same bytes as the run without a budget and the
+    oracle's suffix array; a block that cannot fit the budget is refused up front; with --checkpoint the spilled state
+    survives a stop and a restart."""
+    rng = np.random.default_rng(21)
+    n = 400_003
+    if kind == "english":
+        words = [b"the", b"of", b"and", b"suffix", b"array", b"block", b"stream", b"gap", b"merge", b"a"]
+        t = np.frombuffer(b" ".join(words[i] for i in rng.integers(0, len(words), 120000)), np.uint8)[:n].copy()
+        n = len(t)
+    else:
+        t = {"rand": lambda: rng.integers(0, 255, n, dtype=np.uint8), "sig3": lambda: rng.integers(0, 3, n, dtype=np.uint8),
+             "per3": lambda: np.frombuffer((b"abc" * (n // 3 + 1))[:n], np.uint8).copy()}[kind]()
+    f = tmp_path / "x.bin"
+    f.write_bytes(bytes(t))
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    ref, out = tmp_path / "ref.sa5", tmp_path / "x.sa5"
+    base = [CLI, "-m", "1G", "--block-size", "70000", "--leaf-size", "9000", "--tail-chunk", "16384", "-v"]
+    r = subprocess.run(base + ["-o", str(ref), str(f)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(base + ["--hbm-limit", "96Mi", "--check=300", "-o", str(out), str(f)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Device memory budget" in r.stderr and "Text stays in host memory" in r.stderr and "merge bitvectors to host memory" in r.stderr
+    assert "check: permutation sum ok, 0 of" in r.stderr and "(on the host" in r.stderr
+    assert out.read_bytes() == ref.read_bytes()
+    assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
+    # a block that needs more than the budget is refused before anything runs
+    r = subprocess.run([CLI, "-m", "1G", "--block-size", "4000000", "--hbm-limit", "64Mi", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 1 and "too large for --hbm-limit" in r.stderr
+    if kind == "rand":      # stop and restart under the budget: the spilled merge bitvectors and gt bits come back from the checkpoint
+        ck = tmp_path / "ck"
+        cmd = base + ["--hbm-limit", "96Mi", "--checkpoint", str(ck), "-o", str(out), str(f)]
+        r = subprocess.run(cmd + ["--stop-after", "3"], input="y\n", capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 3, r.stderr[-2000:]
+        r = subprocess.run(cmd, input="y\n", capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "Resuming from the checkpoint" in r.stderr, r.stderr[-2000:]
+        assert out.read_bytes() == ref.read_bytes()
 
 
 @pytest.mark.gpu

@@ -16,7 +16,9 @@ api.lib().psg_trim()
 env = dict(os.environ, OMP_NUM_THREADS="16")
 block = str(n // 5 + 12345)
 modes = {"default": [], "text-on-host": ["--text-on-host", "--tail-chunk", str(n // 7)], "device-sort": ["--device-sort"],
-         "spill+checkpoint": ["--spill-psa", "--checkpoint", "/tmp/cmp_ck"], "no-device-merge": ["--no-device-merge"]}
+         "spill+checkpoint": ["--spill-psa", "--checkpoint", "/tmp/cmp_ck"], "no-device-merge": ["--no-device-merge"],
+         # the external-memory schedule: a device budget of ~60 bytes per block symbol -- text, gt bits, partial SAs and merge bitvectors in host memory
+         "hbm-limit": ["--hbm-limit", str(max(64 << 20, 60 * (n // 5 + 12345))), "--tail-chunk", str(n // 7)]}
 hashes = {}
 for name, extra in modes.items():
     out = f + "." + name.replace("+", "_") + ".sa5"
