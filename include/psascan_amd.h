@@ -178,6 +178,11 @@ typedef struct {
                                      text_end) is (d_text still points at position 0: d_text = window - text_begin);
                                      a comparison that would read outside fails the call with PSG_EWINDOW -- a text
                                      that stays in host memory is searched through a window per half-block          */
+  const uint8_t *d_text2;         /* optional SECOND window for the searched positions (psg_initial_ranks only): they and */
+  int64_t text2_begin, text2_end; /* what follows them are read from text[text2_begin .. text2_end) (d_text2 points at
+                                     position 0 likewise), the parts' suffixes from the first window -- a rank of the
+                                     block-per-GPU schedule holds its own block and a piece of the far block whose end it
+                                     searches for, not the text in between.  NULL, 0, 0: one window.                */
 } psg_search_ctx;
 #define PSG_EWINDOW (-7)
 /* h_ranks[k] = sum over the parts of #{s in part : text[s..n) < text[h_positions[k]..n)}; positions lie at or

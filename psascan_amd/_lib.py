@@ -42,7 +42,8 @@ class SearchPartC(C.Structure):
 
 class SearchCtxC(C.Structure):
     _fields_ = [("d_text", C.c_void_p), ("n", C.c_int64), ("cmp_end", C.c_int64), ("d_gt_cmp_end", C.c_void_p), ("nparts", C.c_int),
-                ("part", SearchPartC * 2), ("text_begin", C.c_int64), ("text_end", C.c_int64)]
+                ("part", SearchPartC * 2), ("text_begin", C.c_int64), ("text_end", C.c_int64),
+                ("d_text2", C.c_void_p), ("text2_begin", C.c_int64), ("text2_end", C.c_int64)]
 
 
 class StreamArgsC(C.Structure):

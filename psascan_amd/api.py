@@ -121,15 +121,19 @@ class StreamStats:
 PSG_GAP_UNINITIALIZED, PSG_FAIL_IF_UNRESOLVED, PSG_EUNRESOLVED = 1, 2, -6
 
 
-def search_ctx(d_text, n, cmp_end, d_gt_cmp_end, parts, window=None):
+def search_ctx(d_text, n, cmp_end, d_gt_cmp_end, parts, window=None, window2=None):
     """psg_search_ctx: parts = [(beg, size, d_psa_lo, d_psa_hi or None)] (1 or 2 half-blocks below cmp_end);
     d_gt_cmp_end: bit (n - j) = [text[j..) > text[cmp_end..)].  window = (begin, end): d_text holds text[begin..end)
-    only (d_text = pointer to the window's first byte); a comparison that leaves it raises PSG_EWINDOW."""
+    only (d_text = pointer to the window's first byte); a comparison that leaves it raises PSG_EWINDOW.
+    window2 = (d_text2, begin, end): the searched positions are read from a second window (psg_initial_ranks)."""
     sc = SearchCtxC()
     sc.d_text, sc.n, sc.cmp_end, sc.d_gt_cmp_end, sc.nparts = _ptr(d_text), n, cmp_end, _ptr(d_gt_cmp_end), len(parts)
     if window is not None:
         sc.text_begin, sc.text_end = window
         sc.d_text = _ptr(d_text) - window[0]
+    if window2 is not None:
+        sc.d_text2, sc.text2_begin, sc.text2_end = _ptr(window2[0]) - window2[1], window2[1], window2[2]
+        sc._keep2 = window2[0]
     for k, (beg, size, lo, hi) in enumerate(parts):
         sc.part[k].beg, sc.part[k].size, sc.part[k].d_psa_lo, sc.part[k].d_psa_hi = beg, size, _ptr(lo), _ptr(hi)
     sc._keep = (d_text, d_gt_cmp_end, parts)
@@ -368,7 +372,7 @@ class SlicedMergePlan(MergePlan):
         for k, lv in enumerate(levels):
             arr[k].beg, arr[k].size, arr[k].nbits = lv["beg"], lv["size"], lv["nbits"]
             arr[k].d_mbv_words, arr[k].first_word, arr[k].n_words, arr[k].ones_before = _ptr(lv["d_mbv"]), lv["first_word"], lv["n_words"], lv["ones_before"]
-            arr[k].d_psa_lo, arr[k].d_psa_hi, arr[k].psa_first, arr[k].psa_count = _ptr(lv["d_psa"]), None, lv["psa_first"], lv["psa_count"]
+            arr[k].d_psa_lo, arr[k].d_psa_hi, arr[k].psa_first, arr[k].psa_count = _ptr(lv["d_psa"]), _ptr(lv.get("d_psa_hi")), lv["psa_first"], lv["psa_count"]
         self._keep = levels
         self.n = sum(lv["size"] for lv in levels)
         h = C.c_void_p()

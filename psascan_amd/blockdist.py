@@ -25,6 +25,15 @@ shared-GPU rehearsal).  The text is cut into `world` blocks, rank g owns block g
 
 `ops` supplies the compute: HipBlockOps = the C ABI on this rank's GPU; the CPU tests inject oracle-backed
 stand-ins to check the schedule, the indexing of the exchanged bits and the slice arithmetic without a GPU.
+
+BASELINE configs[3] (128 GiB of DNA, 8 blocks of 16 GiB, half-blocks of 2^33 symbols):
+  * partial SAs are 40-bit values in two planes (u32 low words + bytes 32..39): the high plane travels through the
+    search contexts, the merge pieces and the sliced plan like the low one (`wide`);
+  * a rank never holds the whole text: its own block (+ a look-ahead) is resident, the chunk of the current round comes
+    from a TextSource (generated / uploaded one round ahead), and the start ranks of the far chunks are searched through
+    two text windows (psg_search_ctx.d_text2);
+  * the merge runs in `rounds` sub-ranges of every rank's output range, one all-to-all each, so that the exchange
+    buffers are a fraction of the 5 bytes per symbol a rank receives in total.
 """
 import numpy as np
 
@@ -71,12 +80,14 @@ def run(dist, ops, world, rank, n, stats=None):
                 stats.append((rank, q, getattr(st, "last_stats", None)))
         else:
             prev = ops.new_i32(words)
-    hbs = ops.finish(st, n - e)                                 # [{beg, size, mbv, nbits, psa}] left half, right half
+    hbs = ops.finish(st, n - e)                                 # [{beg, size, mbv, nbits, psa, psa_hi}] left half, right half
     return merge_ranges(dist, ops, world, rank, n, bounds, hbs)
 
 
 def merge_ranges(dist, ops, world, rank, n, bounds, my_hbs):
     """Output-range partitioned merge.  my_hbs: this rank's two half-blocks (mbv = None for the very last one)."""
+    S = max(1, int(getattr(ops, "merge_rounds", 1)))                 # sub-ranges per rank: one all-to-all each
+    wide = bool(getattr(ops, "force_wide", False)) or max(bounds[g + 1] - bounds[g] for g in range(world)) // 2 + 1 >= (1 << 32)
     H = 2 * world
     sizes = []
     for g in range(world):
@@ -87,7 +98,12 @@ def merge_ranges(dist, ops, world, rank, n, bounds, my_hbs):
     for h in range(H - 1, -1, -1):
         later[h] = later[h + 1] + sizes[h][1]
     nbits = [later[h] if h + 1 < H else 0 for h in range(H)]     # level h: own elements + everything behind it
-    X = output_cuts(n, world)
+    Xr = output_cuts(n, world)                                        # rank d produces [Xr[d], Xr[d+1])
+    X = []                                                            # ... in S sub-ranges: boundary d * S + s
+    for d in range(world):
+        for k in range(S):
+            X.append(min(Xr[d + 1], Xr[d] + ((Xr[d + 1] - Xr[d]) * k // S + 4095) // 4096 * 4096) if k else Xr[d])
+    X.append(n)
     nb = len(X)
     # ---- positions of the range boundaries on every level: q_0 = X, q_{h+1} = rank1(mbv_h, q_h)
     q = np.array(X, np.int64)
@@ -115,66 +131,128 @@ def merge_ranges(dist, ops, world, rank, n, bounds, my_hbs):
         q = ones
     for h in range(H):
         assert cur[h][0] == 0 and cur[h][-1] == sizes[h][1], (h, cur[h], sizes[h])
-    # ---- what dest d gets of level h: mbv words [fw, lw) and PSA elements [c0, c1)
-    def piece(h, d):
-        c0, c1 = int(cur[h][d]), int(cur[h][d + 1])
+    # ---- what dest d gets of level h in round s: mbv words [fw, lw), PSA elements [c0, c1) (+ their high bytes, packed 4 per word)
+    def piece(h, d, s):
+        j = d * S + s
+        c0, c1 = int(cur[h][j]), int(cur[h][j + 1])
+        hw = (c1 - c0 + 3) // 4 if wide else 0
         if h == H - 1:
-            return 0, 0, c0, c1
-        q0, q1 = int(qs[h][d]), int(qs[h][d + 1])
+            return 0, 0, c0, c1, hw
+        q0, q1 = int(qs[h][j]), int(qs[h][j + 1])
         total_words = (nbits[h] + 31) // 32
         fw = min((q0 // 4096) * 128, total_words)
         lw = min(total_words, (q1 + 31) // 32 + 1)          # + 1: a 32-bit fetch at the range end may look one word ahead
-        return fw, max(fw, lw), c0, c1
+        return fw, max(fw, lw), c0, c1, hw
 
-    send_parts, send_sizes = [], []
-    for d in range(world):
-        tot = 0
-        for k in (0, 1):
-            h = 2 * rank + k
-            fw, lw, c0, c1 = piece(h, d)
-            hb = my_hbs[k]
-            if lw > fw:
-                send_parts.append(ops.mbv_words(hb["mbv"], fw, lw - fw))
-            if c1 > c0:
-                send_parts.append(ops.psa_words(hb["psa"], c0, c1 - c0))
-            tot += (lw - fw) + (c1 - c0)
-        send_sizes.append(tot)
-    recv_sizes = []
-    for src in range(world):
-        tot = 0
-        for k in (0, 1):
-            fw, lw, c0, c1 = piece(2 * src + k, rank)
-            tot += (lw - fw) + (c1 - c0)
-        recv_sizes.append(tot)
-    send_t = ops.cat_i32(send_parts, sum(send_sizes))
-    recv_t = ops.new_i32(max(1, sum(recv_sizes)))
-    if world > 1:
-        ops.before_collective()
-        dist.all_to_all_single(recv_t[: sum(recv_sizes)], send_t[: sum(send_sizes)], recv_sizes, send_sizes)
-        ops.after_collective()
-    else:
-        recv_t = send_t
-    # ---- local merge over the slices
-    levels, off = [], 0
-    for h in range(H):
-        fw, lw, c0, c1 = piece(h, rank)
-        lv = {"beg": sizes[h][0], "size": sizes[h][1], "nbits": nbits[h], "first_word": fw, "n_words": lw - fw,
-              "ones_before": int(ones_al[h][rank]), "psa_first": c0, "psa_count": c1 - c0, "mbv_off": off, "psa_off": off + (lw - fw)}
-        off += (lw - fw) + (c1 - c0)
-        levels.append(lv)
-    x0, x1 = X[rank], X[rank + 1]
-    out = ops.merge_slices(levels, recv_t, x0, x1)
-    return x0, x1, out
+    outs = []
+    for s in range(S):
+        send_parts, send_sizes = [], []
+        for d in range(world):
+            tot = 0
+            for k in (0, 1):
+                h = 2 * rank + k
+                fw, lw, c0, c1, hw = piece(h, d, s)
+                hb = my_hbs[k]
+                if lw > fw:
+                    send_parts.append(ops.mbv_words(hb["mbv"], fw, lw - fw))
+                if c1 > c0:
+                    send_parts.append(ops.psa_words(hb["psa"], c0, c1 - c0))
+                    if wide:
+                        send_parts.append(ops.psa_hi_words(hb.get("psa_hi"), c0, c1 - c0))
+                tot += (lw - fw) + (c1 - c0) + hw
+            send_sizes.append(tot)
+        recv_sizes = []
+        for src in range(world):
+            tot = 0
+            for k in (0, 1):
+                fw, lw, c0, c1, hw = piece(2 * src + k, rank, s)
+                tot += (lw - fw) + (c1 - c0) + hw
+            recv_sizes.append(tot)
+        send_t = ops.cat_i32(send_parts, sum(send_sizes))
+        recv_t = ops.new_i32(max(1, sum(recv_sizes)))
+        if world > 1:
+            ops.before_collective()
+            dist.all_to_all_single(recv_t[: sum(recv_sizes)], send_t[: sum(send_sizes)], recv_sizes, send_sizes)
+            ops.after_collective()
+        else:
+            recv_t = send_t
+        # ---- local merge over the slices
+        levels, off = [], 0
+        j = rank * S + s
+        for h in range(H):
+            fw, lw, c0, c1, hw = piece(h, rank, s)
+            lv = {"beg": sizes[h][0], "size": sizes[h][1], "nbits": nbits[h], "first_word": fw, "n_words": lw - fw,
+                  "ones_before": int(ones_al[h][j]), "psa_first": c0, "psa_count": c1 - c0, "mbv_off": off, "psa_off": off + (lw - fw),
+                  "psa_hi_off": (off + (lw - fw) + (c1 - c0)) if wide else None}
+            off += (lw - fw) + (c1 - c0) + hw
+            levels.append(lv)
+        outs.append(ops.merge_slices(levels, recv_t, X[j], X[j + 1]))
+        del send_t, recv_t, send_parts
+    x0, x1 = Xr[rank], Xr[rank + 1]
+    if any(o is None for o in outs):
+        return x0, x1, None
+    return x0, x1, (np.concatenate(outs) if len(outs) > 1 else outs[0])
+
+
+class WholeText:
+    """TextSource for a text that is resident in HBM as a whole (small texts, tests)."""
+
+    def __init__(self, d_text, n):
+        self.d_text, self.n = d_text, n
+
+    def window(self, lo, hi):
+        """-> (pointer to text position 0, first, last): text[first .. last) is readable there, first <= lo, last >= hi"""
+        return self.d_text.ptr, 0, self.n
+
+    def prefetch(self, lo, hi):
+        pass
+
+
+class ChunkedText:
+    """TextSource for a text that no rank holds as a whole: `load(lo, hi) -> DeviceBuffer` with text[lo .. hi) produces
+    any range (bench: the seeded generator on the device; a real run: an upload from the memory-mapped file).  The rank's
+    own block (+ look-ahead) is loaded once and kept; other ranges live in two rotating buffers, the next one loaded
+    while the current one is in use (prefetch)."""
+
+    def __init__(self, load, n, own_lo, own_hi):
+        self.load, self.n = load, n
+        self.own = (load(own_lo, own_hi), own_lo, own_hi)
+        self.slots = []                                     # [(buffer, lo, hi)], at most two
+
+    def _find(self, lo, hi):
+        for buf, a, b in [self.own] + self.slots:
+            if a <= lo and hi <= b:
+                return buf, a, b
+        return None
+
+    def prefetch(self, lo, hi):
+        if self._find(lo, hi) is None:
+            if len(self.slots) >= 2:
+                self.slots.pop(0)[0].free()
+            self.slots.append((self.load(lo, hi), lo, hi))
+
+    def window(self, lo, hi):
+        self.prefetch(lo, hi)
+        buf, a, b = self._find(lo, hi)
+        return buf.ptr - a, a, b
 
 
 class HipBlockOps:
     """The schedule's compute on this rank's GPU through the C ABI.  comm = "cuda": tensors handed to the
-    collectives are torch CUDA tensors (NCCL/RCCL; the library is put on torch's stream by the caller);
-    comm = "cpu": CPU tensors (gloo; data is staged through the library's copies -- shared-GPU rehearsal)."""
+    collectives are torch CUDA tensors (NCCL/RCCL; the library is put on torch's stream by the caller, so kernels and
+    collectives are ordered on that one stream without device-wide syncs); comm = "cpu": CPU tensors (gloo; data is
+    staged through the library's copies -- shared-GPU rehearsal).  text: a DeviceBuffer with the whole text or a
+    TextSource (WholeText / ChunkedText)."""
+    LOOKAHEAD = 1 << 16                                         # text kept behind a block / a searched position for comparisons that read on
 
-    def __init__(self, torch, api, d_text, n, sorter, comm="cuda", max_chains=0, keep_output_on_device=False):
-        self.torch, self.api, self.d_text, self.n, self.sorter, self.comm, self.max_chains = torch, api, d_text, n, sorter, comm, max_chains
+    def __init__(self, torch, api, text, n, sorter, comm="cuda", max_chains=0, keep_output_on_device=False, merge_rounds=1, force_wide=False,
+                 check_text=None):
+        self.torch, self.api, self.n, self.sorter, self.comm, self.max_chains = torch, api, n, sorter, comm, max_chains
+        self.text = text if hasattr(text, "window") else WholeText(text, n)
         self.keep_output_on_device = keep_output_on_device
+        self.merge_rounds, self.force_wide = merge_rounds, force_wide
+        self.check_text = check_text                           # (d_text of the whole text, samples): every round's output is checked on the device
+        self.check_acc = [0, 0]                                # bad pairs, sum of entries mod 2^64
         self.d_out = None
 
     # ---- tensors
@@ -194,13 +272,12 @@ class HipBlockOps:
         return self.torch.cat(parts) if parts else self.new_i32(1)
 
     def before_collective(self):
-        self.api.sync()
-        if self.comm == "cuda":
-            self.torch.cuda.synchronize()
+        # every library call has completed when it returns and, with comm = "cuda", library and collectives share one
+        # stream: nothing to wait for (round 2 drained the whole device on both sides of every collective)
+        pass
 
     def after_collective(self):
-        if self.comm == "cuda":
-            self.torch.cuda.synchronize()
+        pass
 
     def _to_dev(self, t, nwords):
         """device pointer of an int32 tensor's first nwords (uploads CPU tensors)"""
@@ -223,13 +300,32 @@ class HipBlockOps:
         buf = self.api.zeros(4 * words)
         return None, buf.ptr, (lambda: self._from_dev(buf, words))
 
+    def _text_ptr(self, lo, hi):
+        """device pointer of text position `lo` inside a window that holds text[lo .. hi)"""
+        base, a, b = self.text.window(lo, min(self.n, hi))
+        return base + lo
+
+    def _search_ctx(self, lo, hi, parts, pattern=None):
+        """search context over the window that holds text[lo .. hi) (comparisons read on to the end of the text);
+        pattern = (pos, len): the searched position lies in a second window"""
+        api, n = self.api, self.n
+        base, a, b = self.text.window(lo, min(n, hi))
+        win = None if (a == 0 and b == n) else (a, b)
+        w2 = None
+        if pattern is not None and win is not None and not (a <= pattern[0] and pattern[0] + pattern[1] <= b):
+            p0, p1 = pattern[0], min(n, pattern[0] + pattern[1])
+            base2, a2, b2 = self.text.window(p0, p1)
+            w2 = (base2 + a2, a2, b2)
+        return api.search_ctx(base + (a if win else 0), n, n, None, parts, window=win, window2=w2)
+
     def sym(self, pos):
-        return int(self.api.download(self.d_text, np.uint8, 1, pos)[0])
+        return int(self.api.download(self._text_ptr(pos, pos + 1), np.uint8, 1)[0])
 
     # ---- local phase
     def local_block(self, b, mid, e, words):
         api, n = self.api, self.n
         ls, rs, bs = mid - b, e - mid, e - b
+        own_hi = min(n, e + self.LOOKAHEAD)
 
         class State:
             pass
@@ -242,9 +338,9 @@ class HipBlockOps:
         rankL = api.rank_build(L["bwt"], ls)
         gapA = api.gap_array(ls, fill=None)
         gtA = api.zeros(4 * ((rs + 31) // 32 + 4))
-        scA = api.search_ctx(self.d_text, n, n, None, [(b, ls, L["psa_lo"], None)])     # direct comparison to the end of the text
+        scA = self._search_ctx(b, own_hi, [(b, ls, L["psa_lo"], L.get("psa_hi"))])     # direct comparison, reading on behind the block
         initA = int(api.initial_ranks(scA, [e])[0])
-        api.stream_gap(rankL, L["i0"], st.last_left, self.d_text.at(mid), rs, R["gt_begin"], initA, gapA, gtA, self.max_chains, fresh_gap=True)
+        api.stream_gap(rankL, L["i0"], st.last_left, self._text_ptr(mid, e), rs, R["gt_begin"], initA, gapA, gtA, self.max_chains, fresh_gap=True)
         rankL.free()
         st.bvA = api.zeros(4 * ((bs + 31) // 32 + 2))
         assert api.gap_to_bitvector(gapA, ls, st.bvA, bs) == bs
@@ -261,26 +357,44 @@ class HipBlockOps:
             st.rank = api.rank_build(d_bbwt, bs)
             d_bbwt.free()
             st.gap = api.gap_array(bs, fill=None)
+        for hb in (L, R):                                     # BWT and gt bits of the halves are not needed any more
+            for key in ("bwt", "gt_begin"):
+                if hb.get(key) is not None and hb.get("keep_inputs") is not True:
+                    hb[key].free()
+                    hb[key] = None
         return st
 
     def start_ranks(self, st, positions):
-        sc = self.api.search_ctx(self.d_text, self.n, self.n, None, [(st.b, st.mid - st.b, st.L["psa_lo"], None), (st.mid, st.e - st.mid, st.R["psa_lo"], None)])
-        return self.api.initial_ranks(sc, positions)
+        """rank of text[p..) among the block's suffixes for the ends p of the far chunks: string search through two text
+        windows -- the block (+ look-ahead) and a piece behind p (em_compute_initial_ranks.hpp:222-319)"""
+        parts = [(st.b, st.mid - st.b, st.L["psa_lo"], st.L.get("psa_hi")), (st.mid, st.e - st.mid, st.R["psa_lo"], st.R.get("psa_hi"))]
+        out = []
+        for p in positions:
+            if p >= self.n:
+                out.append(0)                                 # the empty suffix is the smallest
+                continue
+            sc = self._search_ctx(st.b, min(self.n, st.e + self.LOOKAHEAD), parts, pattern=(p, self.LOOKAHEAD))
+            out.append(int(self.api.initial_ranks(sc, [p])[0]))
+        return out
 
     def stream(self, st, cb, ce, gt_in_t, start_rank, words, first):
         api = self.api
         T = ce - cb
         keep, gin = self._to_dev(gt_in_t, (T + 31) // 32 + 1)
         _, gout, done = self._slice_out(words)
-        _, s = api.stream_gap(st.rank, st.block_i0, st.last, self.d_text.at(cb), T, gin, start_rank, st.gap, gout, self.max_chains, fresh_gap=first)
+        tail = self._text_ptr(cb, ce)
+        nxt = ce + (ce - cb)
+        _, s = api.stream_gap(st.rank, st.block_i0, st.last, tail, T, gin, start_rank, st.gap, gout, self.max_chains, fresh_gap=first)
+        if ce < self.n:
+            self.text.prefetch(ce, min(self.n, nxt))          # the next round's chunk (a TextSource that loads in the background overlaps it with the collective)
         st.last_stats = s
         return done()
 
     def finish(self, st, T):
         api = self.api
         ls, rs, bs = st.mid - st.b, st.e - st.mid, st.e - st.b
-        L = {"beg": st.b, "size": ls, "psa": st.L["psa_lo"], "mbv": None, "nbits": 0}
-        R = {"beg": st.mid, "size": rs, "psa": st.R["psa_lo"], "mbv": None, "nbits": 0}
+        L = {"beg": st.b, "size": ls, "psa": st.L["psa_lo"], "psa_hi": st.L.get("psa_hi"), "mbv": None, "nbits": 0}
+        R = {"beg": st.mid, "size": rs, "psa": st.R["psa_lo"], "psa_hi": st.R.get("psa_hi"), "mbv": None, "nbits": 0}
         if st.rank is None:                                   # last block: the left half's gap is its merge bitvector
             L["mbv"], L["nbits"] = st.bvA, bs
             return [L, R]
@@ -296,27 +410,51 @@ class HipBlockOps:
     def rank1(self, mbv, nbits, positions):
         return self.api.bits_rank1(mbv, nbits, positions)
 
-    def mbv_words(self, mbv, first_word, n_words):
+    def _words_from(self, src, byte_off, n_words, nbytes=None):
+        """int32 tensor with n_words words copied from a device buffer or a host array (partial SAs that live in pinned
+        host memory) at byte_off; nbytes < 4 * n_words: the rest is zero"""
+        nbytes = 4 * n_words if nbytes is None else nbytes
+        if isinstance(src, np.ndarray):
+            raw = np.zeros(4 * n_words, np.uint8)
+            raw[:nbytes] = src.view(np.uint8)[byte_off: byte_off + nbytes]
+            return self.torch.from_numpy(raw.view(np.int32)).to(self.comm)
         if self.comm == "cuda":
-            t = self.torch.empty(n_words, dtype=self.torch.int32, device="cuda")
-            self.api.check(self.api.lib().psg_d2d(t.data_ptr(), mbv.ptr + 4 * first_word, 4 * n_words))
-            self.api.sync()
+            t = self.torch.zeros(n_words, dtype=self.torch.int32, device="cuda")
+            self.api.check(self.api.lib().psg_d2d(t.data_ptr(), src.ptr + byte_off, nbytes))
             return t
-        return self.torch.from_numpy(self.api.download(mbv, np.int32, n_words, 4 * first_word))
+        raw = np.zeros(4 * n_words, np.uint8)
+        raw[:nbytes] = self.api.download(src, np.uint8, nbytes, byte_off)
+        return self.torch.from_numpy(raw.view(np.int32))
+
+    def mbv_words(self, mbv, first_word, n_words):
+        return self._words_from(mbv, 4 * first_word, n_words)
 
     def psa_words(self, psa, first, count):
-        return self.mbv_words(psa, first, count)
+        return self._words_from(psa, 4 * first, count)
+
+    def psa_hi_words(self, psa_hi, first, count):
+        """bits 32..39 of `count` entries, four per word (zeros for a half-block below 2^32 symbols)"""
+        nw = (count + 3) // 4
+        if psa_hi is None:
+            return self.new_i32(nw)
+        return self._words_from(psa_hi, first, nw, count)
 
     def merge_slices(self, levels, recv_t, x0, x1):
         api = self.api
         keep, base = self._to_dev(recv_t, recv_t.numel())
         descs = []
         for lv in levels:
-            descs.append(dict(lv, d_mbv=(base + 4 * lv["mbv_off"]) if lv["n_words"] else None, d_psa=(base + 4 * lv["psa_off"]) if lv["psa_count"] else None))
+            descs.append(dict(lv, d_mbv=(base + 4 * lv["mbv_off"]) if lv["n_words"] else None, d_psa=(base + 4 * lv["psa_off"]) if lv["psa_count"] else None,
+                              d_psa_hi=(base + 4 * lv["psa_hi_off"]) if (lv.get("psa_hi_off") is not None and lv["psa_count"]) else None))
         plan = api.SlicedMergePlan(descs)
         d_out = api.DeviceBuffer(5 * (x1 - x0) + 16)
         plan.run(x0, x1 - x0, d_out)
         plan.free()
+        if self.check_text is not None and x1 > x0:
+            from . import extras
+            bad, sm = extras.check_sa5(self.check_text[0], self.n, d_out, x1 - x0, samples=self.check_text[1], seed=7 + x0 % 1000)
+            self.check_acc[0] += bad
+            self.check_acc[1] = (self.check_acc[1] + sm) % (1 << 64)
         self.d_out = d_out
         if self.keep_output_on_device:
             return None

@@ -27,6 +27,8 @@ struct SearchParams {
   i64 *rank;
   i64 text_end;             // text[.. text_end) is readable (= n when the whole text is on the device)
   int *fail;                // set when a comparison would have to read at or behind text_end
+  const u8 *text2;          // the pattern side reads here (a second window, addressed by absolute position like `text`); = text with one window
+  i64 text2_end;
 };
 
 __device__ __forceinline__ u64 load8_unaligned(const u8 *p) {
@@ -53,16 +55,16 @@ __device__ __forceinline__ bool suffix_less_wave(const SearchParams &P, i64 s, i
       return g;
     }
     i64 chunk = std::min<i64>(512, std::min(rem_p, rem_s));
-    const i64 avail = P.text_end - (p + k);                 // p > s: the pattern side reaches the window's end first
+    const i64 avail = std::min(P.text2_end - (p + k), P.text_end - (s + k));   // either side may reach the end of its window
     if (avail < chunk) {
       if (avail <= 0) { if (lane == 0) *P.fail = 1; lcp_out = k; return false; }
       chunk = avail;
     }
     const i64 off = (i64)lane * 8;
     u64 a = 0, b = 0;
-    if (off + 8 <= chunk) { a = load8_unaligned(P.text + s + k + off); b = load8_unaligned(P.text + p + k + off); }
+    if (off + 8 <= chunk) { a = load8_unaligned(P.text + s + k + off); b = load8_unaligned(P.text2 + p + k + off); }
     else if (off < chunk) {
-      for (int q = 0; q < (int)(chunk - off); ++q) { a |= (u64)P.text[s + k + off + q] << (8 * q); b |= (u64)P.text[p + k + off + q] << (8 * q); }
+      for (int q = 0; q < (int)(chunk - off); ++q) { a |= (u64)P.text[s + k + off + q] << (8 * q); b |= (u64)P.text2[p + k + off + q] << (8 * q); }
     }
     const u64 x = a ^ b;
     const u64 mism = __ballot(x != 0);
@@ -136,6 +138,11 @@ int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i6
   for (int t = 0; windowed && t < sc->nparts; ++t)
     PSG_REQUIRE(sc->part[t].beg >= sc->text_begin && sc->part[t].beg + sc->part[t].size <= sc->text_end, "search context: a part lies outside the text window");
   P.text_end = windowed ? sc->text_end : sc->n;
+  P.text2 = P.text; P.text2_end = P.text_end;
+  if (sc->d_text2) {
+    PSG_REQUIRE(windowed && sc->text2_begin >= 0 && sc->text2_begin <= sc->text2_end && sc->text2_end <= sc->n, "search context: bad second text window");
+    P.text2 = sc->d_text2; P.text2_end = sc->text2_end;
+  }
   P.fail = search_fail_flag();
   if (!P.fail) { set_error("search: flag allocation failed"); return PSG_ENOMEM; }
   if (npos == 0) return 0;
@@ -150,6 +157,7 @@ extern "C" int psg_initial_ranks(const psg_search_ctx *sc, const int64_t *h_posi
   PSG_REQUIRE(h_positions && h_ranks && count >= 0, "psg_initial_ranks");
   if (count == 0) return 0;
   for (i64 k = 0; k < count; ++k) PSG_REQUIRE(h_positions[k] >= 0 && h_positions[k] <= sc->n, "psg_initial_ranks: position out of range");
+  if (sc->d_text2) for (i64 k = 0; k < count; ++k) PSG_REQUIRE(h_positions[k] >= sc->text2_begin, "psg_initial_ranks: a searched position lies in front of the second text window");
   DevBuf pos, rk;
   int rc;
   if ((rc = pos.alloc(count * 8)) || (rc = rk.alloc(count * 8))) return rc;

@@ -15,7 +15,8 @@ def _words(bits_u8_packed, words):
 
 
 class OracleBlockOps:
-    def __init__(self, text):
+    def __init__(self, text, merge_rounds=1, force_wide=False):
+        self.merge_rounds, self.force_wide = merge_rounds, force_wide
         self.t = np.ascontiguousarray(text, np.uint8)
         self.n = len(self.t)
         self.sa = orc.suffix_array(self.t)
@@ -92,6 +93,10 @@ class OracleBlockOps:
     def psa_words(self, psa, first, count):
         return torch.from_numpy(np.ascontiguousarray(psa[first: first + count]).astype(np.uint32).view(np.int32).copy())
 
+    def psa_hi_words(self, psa_hi, first, count):
+        """bits 32..39 of the entries, four per word: all zero at test sizes -- a marker byte 0 is what must come back"""
+        return torch.zeros((count + 3) // 4, dtype=torch.int32)
+
     def merge_slices(self, levels, recv_t, x0, x1):
         """the level walk of merge.hpp:123-158 in closed form, on the slices only"""
         buf = recv_t.numpy()
@@ -101,6 +106,9 @@ class OracleBlockOps:
         H = len(levels)
         for h, lv in enumerate(levels):
             psa = buf[lv["psa_off"]: lv["psa_off"] + lv["psa_count"]].view(np.uint32).astype(np.int64)
+            if lv.get("psa_hi_off") is not None:           # wide: the high plane travels behind the low one
+                hi = buf[lv["psa_hi_off"]: lv["psa_hi_off"] + (lv["psa_count"] + 3) // 4].view(np.uint8)[: lv["psa_count"]].astype(np.int64)
+                psa = psa + (hi << 32)
             if h == H - 1:
                 idx = q0 + np.arange(len(slots)) - lv["psa_first"]
                 assert len(slots) == 0 or (idx.min() >= 0 and idx.max() < lv["psa_count"])

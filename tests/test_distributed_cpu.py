@@ -157,7 +157,9 @@ WORKER_BLOCKS = textwrap.dedent("""
     for name in ("sig4_with_zero", "alla", "per3", "fib", "rand1m"):
         t = gin.GENERATORS[name]()
         n = len(t)
-        ops = OracleBlockOps(t)
+        # (the short texts also run the merge in three sub-ranges per rank with the high plane of 40-bit partial SAs on the
+        #  wire: configs[3]'s form of the exchange)
+        ops = OracleBlockOps(t, merge_rounds=1 if name == "rand1m" else 3, force_wide=name != "rand1m")
         x0, x1, sa5 = BD.run(dist, ops, world, rank, n)
         assert len(sa5) == 5 * (x1 - x0)
         # every rank contributes its output range; rank 0 assembles the file and compares with the reference's hash

@@ -482,6 +482,32 @@ def test_initial_ranks_vs_definition(A, kind):
     assert np.array_equal(A.initial_ranks(scZ, posZ), [rank_of(p, e, n - 100) for p in posZ])
 
 
+def test_search_with_two_text_windows(A):
+    """psg_search_ctx.d_text2: a rank of the block-per-GPU schedule holds its own block (+ a look-ahead) and a piece of a
+    far block -- the suffixes of the block are read from the first window, the searched positions from the second one.
+    Ranks equal the whole-text search; a comparison that would leave either window raises PSG_EWINDOW."""
+    rng = np.random.default_rng(29)
+    x = rng.integers(0, 250, 8_000, dtype=np.uint8)
+    t = np.concatenate([rng.integers(0, 250, 6_000, dtype=np.uint8), x, rng.integers(0, 250, 30_000, dtype=np.uint8), x, rng.integers(0, 250, 9_000, dtype=np.uint8)])
+    n = len(t)                                              # x at 6000..14000 and at 44000..52000
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    b, e = 2_000, 12_000                                    # the block ends inside the first copy of x
+    psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+    d_psa = A.upload(psa.astype(np.uint32))
+    positions = np.array([44_000, 44_001, 47_000, 50_000, 53_000], np.int64)   # inside / behind the second copy
+    want = np.array([int((isa[b:e] < isa[p]).sum()) for p in positions])
+    for w1_end, w2, ok in ((24_000, (44_000, 56_000), True), (24_000, (44_000, 51_000), False), (13_000, (44_000, 56_000), False)):
+        win1 = A.upload(t[b:w1_end], pad_to=64)
+        win2 = A.upload(t[w2[0]:w2[1]], pad_to=64)
+        sc = A.search_ctx(win1, n, n, None, [(b, e - b, d_psa, None)], window=(b, w1_end), window2=(win2, w2[0], w2[1]))
+        if ok:
+            assert np.array_equal(A.initial_ranks(sc, positions), want)
+        else:
+            with pytest.raises(Exception, match="window"):
+                A.initial_ranks(sc, positions)
+
+
 @pytest.mark.parametrize("kind", ["alla", "per3", "fib", "zeros", "repeats"])
 @pytest.mark.parametrize("mode", ["atomic", "log"])
 def test_stream_gap_repetitive_text_resolves_in_one_round(A, monkeypatch, kind, mode):

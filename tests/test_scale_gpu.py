@@ -112,11 +112,30 @@ from psascan_amd import api, extras, blockdist as BD
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 psascan_amd.lib(0)                                   # every rank on the one GPU of this box (rehearsal)
-for mode, n in ((extras.MODE_BYTES255, 3_000_017), (extras.MODE_ENGLISH, 2_500_000), (extras.MODE_DNA, 1_999_999)):
+for case, (mode, n) in enumerate(((extras.MODE_BYTES255, 3_000_017), (extras.MODE_ENGLISH, 2_500_000), (extras.MODE_DNA, 1_999_999))):
     d_text = extras.gen_text(n, mode, 0, seed=21)
-    ops = BD.HipBlockOps(torch, api, d_text, n, extras.DeviceSorter(d_text, n), comm="cpu", max_chains=4096)
+    if case == 0:
+        ops = BD.HipBlockOps(torch, api, d_text, n, extras.DeviceSorter(d_text, n), comm="cpu", max_chains=4096)
+    else:
+        # BASELINE configs[3]'s form of the schedule at a small size: no rank holds the whole text (own block + look-ahead
+        # resident, the chunk of a round loaded into rotating buffers, far start ranks searched through two text windows),
+        # partial SAs carry a high plane (forced: all zero here), the merge runs in three sub-ranges per rank; the DNA case
+        # also forces the 40-bit rank log and many superblocks in the rank structure
+        host_text = api.download(d_text, np.uint8, n)
+        bounds = BD.block_bounds(n, world)
+        b, e = bounds[rank], bounds[rank + 1]
+        src = BD.ChunkedText(lambda lo, hi: api.upload(host_text[lo:hi], pad_to=64), n, b, min(n, e + BD.HipBlockOps.LOOKAHEAD))
+        base = extras.DeviceSorter(d_text, n)
+        def sorter(text, hb, he, gt_tail, base=base):
+            r = base(text, hb, he, gt_tail)
+            r["psa_hi"] = api.zeros(he - hb + 16)
+            return r
+        if case == 2:
+            os.environ["PSG_LOG_WIDE"] = "1"; os.environ["PSG_SM_SB_SHIFT"] = "14"
+        ops = BD.HipBlockOps(torch, api, src, n, sorter, comm="cpu", max_chains=4096, merge_rounds=3, force_wide=True)
     stats = []
     x0, x1, sa5 = BD.run(dist, ops, world, rank, n, stats)
+    os.environ.pop("PSG_LOG_WIDE", None); os.environ.pop("PSG_SM_SB_SHIFT", None)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([len(sa5)], dtype=torch.int64))
     mx = max(int(s) for s in sizes)
@@ -137,7 +156,9 @@ print("WORKER_OK", rank)
 @pytest.mark.parametrize("world", [2, 3])
 def test_block_per_gpu_schedule_real_kernels(gpu_lib, tmp_path, world):
     """psascan_amd.blockdist with the real kernels: `world` processes share this box's one GPU and talk over gloo
-    (the same schedule runs over RCCL on a multi-GPU node).  Output compared with the oracle's suffix array."""
+    (the same schedule runs over RCCL on a multi-GPU node).  Three texts: the plain form (whole text resident), and twice
+    the form BASELINE configs[3] needs -- chunked text with two-window start-rank search, 40-bit partial SAs in two planes
+    through the exchange, merge in sub-ranges, wide rank log.  Output compared with the oracle's suffix array."""
     import os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
