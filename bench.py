@@ -663,29 +663,83 @@ def config2(args, ctx, n, block):
 
 
 def config_blocks(args, ctx, block):
-    """N > 1: north_star's multi-GPU split (psascan_amd/blockdist.py) -- one block of `block` symbols per GPU, one
-    all-gather of the gt slices per round over RCCL, output-range partitioned merge.  Weak scaling in the data a GPU
-    holds (text = N blocks); the half-block suffix sorts are prepared on the device before the timed region."""
+    """N > 1: north_star's multi-GPU split (psascan_amd/blockdist.py) in BASELINE configs[3]'s shape -- DNA, one block of
+    `block` symbols per GPU (16 GiB: half-blocks of 2^33 symbols, 40-bit partial SAs), one all-gather of the gt slices per
+    round over RCCL, output-range partitioned merge in sub-ranges.  Weak scaling in the data a GPU holds (text = N blocks).
+    No rank holds the whole text: block q is the seeded generator's output for seed 1000 + q, a rank keeps its own block
+    (+ look-ahead) and produces the chunk of a round on its device when the round needs it (a real run uploads it from
+    the memory-mapped file).  Untimed preparation: the suffix sort of the rank's two half-blocks (pieces of 2^31 merged
+    with the hot path), the start ranks found by string search while the partial SAs are on the device (pass A's and
+    the far chunks': a handful of searches), the partial SAs moved to pinned host memory -- where the host sorter of
+    construct_sa leaves them; the merge pieces go up from there inside the timed step."""
     rank, world, local, dist, torch, np, api, extras, L, log = ctx
     from psascan_amd import blockdist as BD
     n = block * world
     mode = {"bytes": extras.MODE_BYTES255, "dna": extras.MODE_DNA, "english": extras.MODE_ENGLISH}[args.text]
     t0 = time.time()
-    d_text = extras.gen_text(n, mode, 0, seed=3)          # every rank holds the text (it streams the chunks of all blocks to its right)
     bounds = BD.block_bounds(n, world)
     b, e = bounds[rank], bounds[rank + 1]
     mid = b + (e - b) // 2
-    prepared = {(hb, he): extras.sort_halfblock(d_text, n, hb, he) for hb, he in ((mid, e), (b, mid))}
+    LOOK = BD.HipBlockOps.LOOKAHEAD
+
+    def load(lo, hi):
+        """text[lo .. hi) on the device: every block is the generator's output for its own seed (prefix-consistent)"""
+        d = api.zeros((hi - lo + 63) // 64 * 64 + 64)
+        for q in range(world):
+            a, z = max(lo, bounds[q]), min(hi, bounds[q + 1])
+            if a < z:
+                assert a == bounds[q], "ranges start on block boundaries"
+                extras.gen_text(z - a, mode, 0, seed=1000 + q, d_text=d.ptr + (a - lo))
+        return d
+    own_hi = min(n, e + LOOK)
+    src = BD.ChunkedText(load, n, b, own_hi)
+    base, wlo, whi = src.window(b, own_hi)
+    comm = os.environ.get("PSASCAN_COMM") or ("cuda" if os.environ.get("PSASCAN_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+    wide = (e - b) // 2 + 1 >= (1 << 32)
+    rounds = max(1, int(os.environ.get("PSASCAN_MERGE_ROUNDS", "0")) or -(-5 * (e - b) // (8 << 30)))   # ~8 GiB of pieces per all-to-all
+    prepared, pins = {}, []
+    for hb, he in ((mid, e), (b, mid)):
+        r = extras.sort_halfblock_pieces(base, own_hi, (b, own_hi), hb, he, piece_max=int(os.environ.get("PSASCAN_TEST_PIECE_MAX", str(1 << 31))))
+        ent = {"device": True, "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb, "keep_inputs": True}
+        prepared[(hb, he)] = (r, ent)
+    # start ranks while the partial SAs are on the device: pass A's (rank of text[e..) among the left half's suffixes) and the
+    # far chunks' (rank of text[e_q..) among the block's suffixes)
+    tmp_ops = BD.HipBlockOps(torch, api, src, n, None, comm=comm)
+    (rR, entR), (rL, entL) = prepared[(mid, e)], prepared[(b, mid)]
+    scA = tmp_ops._search_ctx(b, own_hi, [(b, mid - b, rL["psa_lo"], rL.get("psa_hi"))])
+    entL["initA"] = int(api.initial_ranks(scA, [e])[0])
+
+    class _St:
+        pass
+    st0 = _St()
+    st0.b, st0.mid, st0.e = b, mid, e
+    st0.L, st0.R = {"psa_lo": rL["psa_lo"], "psa_hi": rL.get("psa_hi")}, {"psa_lo": rR["psa_lo"], "psa_hi": rR.get("psa_hi")}
+    ends = [bounds[q + 1] for q in range(rank + 1, world)]
+    entL["start_ranks"] = dict(zip(ends, tmp_ops.start_ranks(st0, ends))) if ends else {}
+    for (r, ent) in (prepared[(mid, e)], prepared[(b, mid)]):     # partial SAs -> pinned host memory
+        sz = ent["size"]
+        pa = api.PinnedArray(sz, np.uint32)
+        api.check(L.psg_d2h(pa.ptr, r["psa_lo"].ptr, 4 * sz))
+        r["psa_lo"].free()
+        ent["psa_lo"] = pa.array
+        pins.append(pa)
+        if r.get("psa_hi") is not None:
+            ph = api.PinnedArray(sz, np.uint8)
+            api.check(L.psg_d2h(ph.ptr, r["psa_hi"].ptr, sz))
+            r["psa_hi"].free()
+            ent["psa_hi"] = ph.array
+            pins.append(ph)
+    L.psg_trim()
     api.sync()
-    log(f"rank 0 prepared its block of {n / 2 ** 30:.2f} GiB {args.text} text in {time.time() - t0:.1f}s")
+    log(f"rank 0 prepared its block of {n / 2 ** 30:.2f} GiB {args.text} text in {time.time() - t0:.1f}s ({'40-bit' if wide else '32-bit'} partial SAs, merge in {rounds} rounds)")
 
     def replay(text, hb, he, gt_tail):
-        r = prepared[(hb, he)]
-        return {"device": True, "psa_lo": r["psa_lo"], "bwt": r["bwt"], "gt_begin": r["gt_begin"], "i0": r["i0"], "size": he - hb}
+        return dict(prepared[(hb, he)][1])
     # tensors handed to the collectives: CUDA tensors with RCCL; CPU tensors in the gloo rehearsal (PSASCAN_COMM=cuda
     # rehearses the CUDA-tensor code path over gloo)
-    comm = os.environ.get("PSASCAN_COMM") or ("cuda" if os.environ.get("PSASCAN_DIST_BACKEND", "nccl") == "nccl" else "cpu")
-    ops = BD.HipBlockOps(torch, api, d_text, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True)
+    ops = BD.HipBlockOps(torch, api, src, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True, merge_rounds=rounds,
+                         force_wide=any(ent.get("psa_hi") is not None for (_, ent) in prepared.values()))   # (rehearsals force pieces: PSASCAN_TEST_PIECE_MAX)
+    wide = wide or ops.force_wide
     agg = {"suffixes": 0, "kernel_ms": 0.0, "stream_ms": 0.0, "launches": 0}
 
     def step(timed):
@@ -712,16 +766,26 @@ def config_blocks(args, ctx, block):
     tt = torch.tensor([elapsed], dtype=torch.float64, device=comm)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
-    bad, sm = extras.check_sa5(d_text, n, ops.d_out, x1 - x0, samples=1 << 18)
-    v = torch.tensor([bad, sm & 0x7FFFFFFFFFFFFFFF, sm >> 63, agg["suffixes"], int(agg["kernel_ms"] * 1000)], dtype=torch.int64, device=comm)
+    # ---- property check (untimed extra step): possible where the whole text fits next to everything else (rehearsals and
+    # small blocks): every round's output is checked on the device against the whole text -- sampled adjacent pairs in
+    # suffix order, sum of all entries
+    chk = None
+    if n <= (6 << 30) and not args.no_check:
+        d_whole = load(0, n)
+        ops.check_text, ops.check_acc = (d_whole, 1 << 16), [0, 0]
+        step(False)
+        cv = torch.tensor([ops.check_acc[0], ops.check_acc[1] & 0x7FFFFFFFFFFFFFFF, ops.check_acc[1] >> 63], dtype=torch.int64, device=comm)
+        cparts = [torch.empty_like(cv) for _ in range(world)]
+        dist.all_gather(cparts, cv)
+        chk = (sum(int(p[0]) for p in cparts), sum(int(p[1]) + (int(p[2]) << 63) for p in cparts) % (1 << 64))
+        d_whole.free()
+    v = torch.tensor([agg["suffixes"], int(agg["kernel_ms"] * 1000)], dtype=torch.int64, device=comm)
     parts = [torch.empty_like(v) for _ in range(world)]
     dist.all_gather(parts, v)
     if rank != 0:
         return None
-    bad = sum(int(p[0]) for p in parts)
-    sm = sum(int(p[1]) + (int(p[2]) << 63) for p in parts) % (1 << 64)
     K = args.steps
-    suff = sum(int(p[3]) for p in parts) / K
+    suff = sum(int(p[0]) for p in parts) / K
     kern0 = agg["kernel_ms"] / K / 1e3                       # rank 0 streams the most chunks: its kernel time bounds the rounds
     suff0 = agg["suffixes"] / K
     achieved = A_STREAM * suff0 / kern0 / 1e9 if kern0 else 0.0
@@ -729,14 +793,19 @@ def config_blocks(args, ctx, block):
         "metric": "input MB/s, hot path of the block-per-GPU schedule (local pass A + BWT merge + rank, systolic gap-stream rounds with one gt all-gather each, gap split, output-range partitioned merge)",
         "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u40 integer", "data": "synthetic",
-        "config": {"workload": f"{n / 2 ** 30:.2f} GiB {args.text} text, {world} blocks of {block / 2 ** 30:.2f} GiB sharded one per GPU (BASELINE configs[3]'s split at configs[2]'s block size), "
-                               f"{world - 1} rounds, one RCCL all-gather of the gt slices per round, merge partitioned by output range",
-                   "text_bytes": n, "blocks": world, "block_bytes": block, "collectives_per_step": f"{world - 1} all-gathers of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts of {16 * (world + 1)} B, 1 all-to-all"},
+        "config": {"workload": f"configs[3] shape: {n / 2 ** 30:.2f} GiB {args.text} text (seeded, block q = generator seed 1000 + q), {world} blocks of {block / 2 ** 30:.2f} GiB sharded one per GPU "
+                               f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one RCCL all-gather of the gt slices per round, merge partitioned by output range in {rounds} sub-ranges per rank",
+                   "text_bytes": n, "blocks": world, "block_bytes": block,
+                   "resident_per_rank": "own block of text + look-ahead, two chunk buffers, BWT + gt bits of the halves, rank structure, gap array; partial SAs in pinned host memory",
+                   "untimed_preparation": "half-block suffix sorts (device, pieces of 2^31 merged with the hot path), the start ranks found by string search while the partial SAs are on the device",
+                   "collectives_per_step": f"{world - 1} all-gathers of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts, {rounds} all-to-alls"},
         "gap_stream_suffixes_per_s": suff / (elapsed / K), "streamed_suffixes_per_step": suff,
         "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "traffic_source": "rank 0's launches; no PMC pass for the multi-GPU run", "algorithmic_bytes_per_suffix": A_STREAM,
                      "suffixes_per_launch": suff0 / max(1, agg["launches"] / K), "avg_launch_ms": 1e3 * kern0 / max(1, agg["launches"] / K)},
-        "property_check": {"sampled_adjacent_pairs_out_of_order": bad, "sum_matches_permutation": sm == (n * (n - 1) // 2) % (1 << 64)},
+        "property_check": ({"sampled_adjacent_pairs_out_of_order": chk[0], "sum_matches_permutation": chk[1] == (n * (n - 1) // 2) % (1 << 64)} if chk is not None else
+                           {"note": "no rank holds the whole text: the schedule's own invariants (gap sums, chain hand-over ranks, ones of every merge bitvector, cursor totals) are checked in every step; "
+                                    "output parity of this code path against the oracle's suffix array: tests/test_scale_gpu.py::test_block_per_gpu_schedule_real_kernels and the gloo tests"}),
     }
 
 
@@ -769,8 +838,8 @@ def main():
                 res["configs1_step"] = {"value": None, "note": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
     elif world > 1 and cfg != 1:
-        args.text = args.text or "english"
-        block = int((args.block_gib or 4.0) * (1 << 30)) // 4096 * 4096
+        args.text = args.text or "dna"                       # BASELINE configs[3]: DNA, 16 GiB blocks, one per GPU
+        block = int((args.block_gib or 16.0) * (1 << 30)) // 4096 * 4096
         res = config_blocks(args, ctx, block)
         if rank == 0:
             print(json.dumps(res), flush=True)

@@ -21,6 +21,10 @@ int psgx_gen_text(uint8_t *d_text, int64_t n, int mode, int sigma, uint64_t seed
  * at most a few hundred symbols long (random, DNA, the English-like generator).              */
 int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa,
                         uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups);
+/* the same when only the window text[text_begin .. n) is on the device (d_text points at position 0 all the same): a rank
+ * of the block-per-GPU schedule holds its own block and a look-ahead, `n` is where its window ends                    */
+int psgx_sort_halfblock_window(const uint8_t *d_text, int64_t text_begin, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa,
+                               uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups);
 /* property check of `count` uint40 entries: sum of entries mod 2^64, and the number of sampled
  * adjacent pairs (k, k+1) that are NOT in suffix order.                                      */
 int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples,

@@ -338,8 +338,11 @@ class HipBlockOps:
         rankL = api.rank_build(L["bwt"], ls)
         gapA = api.gap_array(ls, fill=None)
         gtA = api.zeros(4 * ((rs + 31) // 32 + 4))
-        scA = self._search_ctx(b, own_hi, [(b, ls, L["psa_lo"], L.get("psa_hi"))])     # direct comparison, reading on behind the block
-        initA = int(api.initial_ranks(scA, [e])[0])
+        if L.get("initA") is not None:                        # found when the half-block was sorted (its partial SA has left the device since)
+            initA = int(L["initA"])
+        else:
+            scA = self._search_ctx(b, own_hi, [(b, ls, L["psa_lo"], L.get("psa_hi"))])     # direct comparison, reading on behind the block
+            initA = int(api.initial_ranks(scA, [e])[0])
         api.stream_gap(rankL, L["i0"], st.last_left, self._text_ptr(mid, e), rs, R["gt_begin"], initA, gapA, gtA, self.max_chains, fresh_gap=True)
         rankL.free()
         st.bvA = api.zeros(4 * ((bs + 31) // 32 + 2))
@@ -367,6 +370,9 @@ class HipBlockOps:
     def start_ranks(self, st, positions):
         """rank of text[p..) among the block's suffixes for the ends p of the far chunks: string search through two text
         windows -- the block (+ look-ahead) and a piece behind p (em_compute_initial_ranks.hpp:222-319)"""
+        cached = st.L.get("start_ranks")                      # {position: rank}: searched when the block was sorted
+        if cached is not None:
+            return [int(cached[int(p)]) for p in positions]
         parts = [(st.b, st.mid - st.b, st.L["psa_lo"], st.L.get("psa_hi")), (st.mid, st.e - st.mid, st.R["psa_lo"], st.R.get("psa_hi"))]
         out = []
         for p in positions:
@@ -414,10 +420,15 @@ class HipBlockOps:
         """int32 tensor with n_words words copied from a device buffer or a host array (partial SAs that live in pinned
         host memory) at byte_off; nbytes < 4 * n_words: the rest is zero"""
         nbytes = 4 * n_words if nbytes is None else nbytes
-        if isinstance(src, np.ndarray):
+        if isinstance(src, np.ndarray):                       # (pinned host memory: one DMA into the tensor)
+            if self.comm == "cuda":
+                t = self.torch.zeros(n_words, dtype=self.torch.int32, device="cuda")
+                if nbytes:
+                    self.api.check(self.api.lib().psg_h2d(t.data_ptr(), src.ctypes.data + byte_off, nbytes))
+                return t
             raw = np.zeros(4 * n_words, np.uint8)
             raw[:nbytes] = src.view(np.uint8)[byte_off: byte_off + nbytes]
-            return self.torch.from_numpy(raw.view(np.int32)).to(self.comm)
+            return self.torch.from_numpy(raw.view(np.int32))
         if self.comm == "cuda":
             t = self.torch.zeros(n_words, dtype=self.torch.int32, device="cuda")
             self.api.check(self.api.lib().psg_d2d(t.data_ptr(), src.ptr + byte_off, nbytes))

@@ -259,6 +259,19 @@ __global__ __launch_bounds__(PSG_WG) void bwt_gt_kernel(const u8 *text, i64 n, i
   }
 }
 
+static i64 g_sort_text_begin = 0;   // psgx_sort_halfblock_window: only text[text_begin .. n) is on the device
+extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa, uint8_t *d_bwt,
+                                   int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups);
+// the same for a text of which only the window text[text_begin .. n) is resident (d_text still points at position 0):
+// the alphabet is taken from the window, and `n` is the end of the text as the sorter's comparisons see it
+extern "C" int psgx_sort_halfblock_window(const uint8_t *d_text, int64_t text_begin, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa,
+                                          uint8_t *d_bwt, int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups) {
+  PSG_REQUIRE(text_begin >= 0 && text_begin <= beg, "psgx_sort_halfblock_window");
+  g_sort_text_begin = text_begin;
+  const int rc = psgx_sort_halfblock(d_text, n, beg, end, d_psa, d_bwt, i0, d_gt_begin, tie_groups);
+  g_sort_text_begin = 0;
+  return rc;
+}
 extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg, int64_t end, uint32_t *d_psa, uint8_t *d_bwt,
                                    int64_t *i0, uint32_t *d_gt_begin, int64_t *tie_groups) {
   i64 size = end - beg;
@@ -268,7 +281,8 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
   int rc;
   if ((rc = hist.alloc(256 * 4))) return rc;
   PSG_HIP(hipMemsetAsync(hist.p, 0, 256 * 4, stream()));
-  hipLaunchKernelGGL(present_kernel, dim3((unsigned)std::min<i64>(cdiv(n, (i64)PSG_WG * 16), 4096)), dim3(PSG_WG), 0, stream(), d_text, n, hist.as<u32>());
+  hipLaunchKernelGGL(present_kernel, dim3((unsigned)std::min<i64>(cdiv(n - g_sort_text_begin, (i64)PSG_WG * 16), 4096)), dim3(PSG_WG), 0, stream(), d_text + g_sort_text_begin,
+                     n - g_sort_text_begin, hist.as<u32>());
   PSG_HIP(hipGetLastError());
   u32 hflags[256];
   if (int rc_ = psg::copy_d2h(hflags, hist.p, sizeof hflags)) return rc_;

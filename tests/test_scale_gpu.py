@@ -256,3 +256,26 @@ def test_all_modes_write_the_same_sa5(gpu_lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_modes.py"), "256", "english"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("pieces", [False, True])
+def test_bench_block_per_gpu_rehearsal(gpu_lib, pieces):
+    """bench.py --gpus 3 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's one
+    GPU over gloo: BASELINE configs[3]'s form of the schedule -- DNA, chunked text from the seeded generator, start ranks
+    searched through two text windows, partial SAs in pinned host memory, merge in sub-ranges -- at 48 MiB per block.  The
+    property check of the line (sampled adjacent pairs in suffix order + permutation sum over every rank's output) must hold.
+    pieces: every half-block is sorted in pieces merged with the hot path and carries a high plane (the 2^33-symbol
+    half-blocks of 16 GiB blocks, forced at this size)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, PSASCAN_DIST_BACKEND="gloo", PSASCAN_SHARE_GPU="1", PSASCAN_MERGE_ROUNDS="3", OMP_NUM_THREADS="2")
+    if pieces:
+        env["PSASCAN_TEST_PIECE_MAX"] = str(9 << 20)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--block-gib", "0.046875"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["config"]["blocks"] == 3 and "configs[3] shape" in d["config"]["workload"]
+    assert d["property_check"] == {"sampled_adjacent_pairs_out_of_order": 0, "sum_matches_permutation": True}, d["property_check"]
+    assert ("40-bit" in d["config"]["workload"]) == pieces
