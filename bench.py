@@ -738,7 +738,8 @@ def config_blocks(args, ctx, block):
     # tensors handed to the collectives: CUDA tensors with RCCL; CPU tensors in the gloo rehearsal (PSASCAN_COMM=cuda
     # rehearses the CUDA-tensor code path over gloo)
     ops = BD.HipBlockOps(torch, api, src, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True, merge_rounds=rounds,
-                         force_wide=any(ent.get("psa_hi") is not None for (_, ent) in prepared.values()))   # (rehearsals force pieces: PSASCAN_TEST_PIECE_MAX)
+                         force_wide=any(ent.get("psa_hi") is not None for (_, ent) in prepared.values()),   # (rehearsals force pieces: PSASCAN_TEST_PIECE_MAX)
+                         helpers=os.environ.get("PSASCAN_HELPERS", "1") != "0")
     wide = wide or ops.force_wide
     agg = {"suffixes": 0, "kernel_ms": 0.0, "stream_ms": 0.0, "launches": 0}
 
@@ -794,7 +795,9 @@ def config_blocks(args, ctx, block):
         "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u40 integer", "data": "synthetic",
         "config": {"workload": f"configs[3] shape: {n / 2 ** 30:.2f} GiB {args.text} text (seeded, block q = generator seed 1000 + q), {world} blocks of {block / 2 ** 30:.2f} GiB sharded one per GPU "
-                               f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one RCCL all-gather of the gt slices per round, merge partitioned by output range in {rounds} sub-ranges per rank",
+                               f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one RCCL all-gather of the gt slices per round"
+                               + (f", helper ranks (rank N-1-g streams half of rank g's chunks once its own are done; one BWT hand-over and one gap reduce per pair)" if ops.helpers and world >= 3 else "")
+                               + f", merge partitioned by output range in {rounds} sub-ranges per rank",
                    "text_bytes": n, "blocks": world, "block_bytes": block,
                    "resident_per_rank": "own block of text + look-ahead, two chunk buffers, BWT + gt bits of the halves, rank structure, gap array; partial SAs in pinned host memory",
                    "untimed_preparation": "half-block suffix sorts (device, pieces of 2^31 merged with the hot path), the start ranks found by string search while the partial SAs are on the device",

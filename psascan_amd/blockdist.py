@@ -56,6 +56,27 @@ def slice_words(bounds):
     return (max(bounds[g + 1] - bounds[g] for g in range(len(bounds) - 1)) + 31) // 32 + 4
 
 
+def helper_of(world):
+    """Load balancing of the systolic schedule (SURVEY 8e caveat 1, 8f row 4): rank g streams world-1-g chunks, so the
+    high ranks run out of work first.  Rank h = world-1-g HELPS rank g (g < world/2): once h has streamed its own last
+    chunk (round world-h = g+1) it holds a replica of block g's rank structure and streams the right half of rank g's
+    chunk of every later round into a gap array of its own, which rank g adds to its array at the end (the reference's
+    streamers share one gap array among threads, compute_gap.hpp:114-124; across devices that is one reduce per pair).
+    Every rank then streams (world-1)/2 chunks in total; a round still lasts as long as its slowest rank, which gives
+    rounds of 1,1,1,.5,.5,.5,.5 chunk times at world = 8: 5 instead of 7 (utilisation 70 % instead of 50 %)."""
+    return {g: world - 1 - g for g in range(world // 2) if world - 1 - g > g}
+
+
+def helper_active(pairs, g, r, world):
+    """does rank g's helper stream half of rank g's chunk in round r?"""
+    return g in pairs and r >= g + 1 and g + r < world
+
+
+def split_point(cb, ce):
+    """the helper takes [cmid, ce): a multiple of 64 positions, so that gt words do not straddle the two parts"""
+    return ce - ((ce - cb) // 2 + 63) // 64 * 64
+
+
 def run(dist, ops, world, rank, n, stats=None):
     """The whole schedule on this rank.  Returns (x0, x1, sa5 bytes of the output entries [x0, x1))."""
     bounds = block_bounds(n, world)
@@ -66,6 +87,30 @@ def run(dist, ops, world, rank, n, stats=None):
     # start ranks of the chunks this rank will stream: rank of text[e_q..) among the block's suffixes
     chunk_ends = [bounds[q + 1] for q in range(rank + 1, world)]
     start = ops.start_ranks(st, chunk_ends) if chunk_ends else []
+    pairs = helper_of(world) if getattr(ops, "helpers", False) and world >= 3 else {}
+    helping = next((g for g, h in pairs.items() if h == rank), None)
+    hp = None
+    if pairs:
+        # ---- every owner hands its helper the block BWT (one all-to-all: only the pairs carry data) and block_i0, the last
+        # symbol and the start ranks of its chunks (one small all-gather)
+        meta = ops.i64_from(ops.block_meta(st) + [int(x) for x in start] + [0] * (world - len(start)))
+        metas = [ops.new_i64(3 + world) for _ in range(world)]
+        dist.all_gather(metas, meta)
+        send_sizes, recv_sizes = [0] * world, [0] * world
+        bwt_t = ops.new_i32(1)
+        if rank in pairs:
+            bwt_t = ops.export_bwt(st)
+            send_sizes[pairs[rank]] = int(bwt_t.numel())
+        if helping is not None:
+            recv_sizes[helping] = (bounds[helping + 1] - bounds[helping] + 3) // 4
+        recv_t = ops.new_i32(max(1, sum(recv_sizes)))
+        ops.before_collective()
+        dist.all_to_all_single(recv_t[: sum(recv_sizes)], bwt_t[: sum(send_sizes)], recv_sizes, send_sizes)
+        ops.after_collective()
+        if helping is not None:
+            m = ops.to_numpy_i64(metas[helping])
+            hp = ops.import_block(recv_t, bounds[helping], bounds[helping + 1], int(m[0]), int(m[1]), [int(x) for x in m[3:]])
+        del recv_t, bwt_t
     prev = st.own_gt
     for r in range(1, world):
         gathered = [ops.new_i32(words) for _ in range(world)]
@@ -73,13 +118,47 @@ def run(dist, ops, world, rank, n, stats=None):
             ops.before_collective()
             dist.all_gather(gathered, prev)                     # the ONE collective of the round
             ops.after_collective()
+
+        def gt_in_for(x):
+            """gt bits of chunk x + r w.r.t. the end of block x: what rank x+1 (and its helper) wrote one round earlier"""
+            t = gathered[x + 1]
+            if helper_active(pairs, x + 1, r - 1, world):
+                t = ops.bits_or(t, gathered[pairs[x + 1]])
+            return t
         q = rank + r
         if q < world:
-            prev = ops.stream(st, bounds[q], bounds[q + 1], gathered[rank + 1], int(start[q - rank - 1]), words, first=(r == 1))
+            cb, ce = bounds[q], bounds[q + 1]
+            lo_end = split_point(cb, ce) if helper_active(pairs, rank, r, world) else ce
+            prev = ops.stream(st, cb, ce, gt_in_for(rank), int(start[q - rank - 1]), words, first=(r == 1), part=(cb, lo_end))
             if stats is not None:
                 stats.append((rank, q, getattr(st, "last_stats", None)))
+        elif helping is not None and helper_active(pairs, helping, r, world):
+            qh = helping + r
+            cb, ce = bounds[qh], bounds[qh + 1]
+            prev = ops.stream(hp, cb, ce, gt_in_for(helping), hp.start[qh - helping - 1], words, first=not getattr(hp, "streamed", False), part=(split_point(cb, ce), ce))
+            hp.streamed = True
+            if stats is not None:
+                stats.append((rank, qh, getattr(hp, "last_stats", None)))
         else:
             prev = ops.new_i32(words)
+    if pairs:
+        # ---- the helpers' gap arrays go home: one all-to-all (pairs only), added slot by slot
+        send_sizes, recv_sizes = [0] * world, [0] * world
+        gap_t = ops.new_i32(1)
+        if helping is not None and getattr(hp, "streamed", False):
+            gap_t = ops.export_gap(hp)
+            send_sizes[helping] = int(gap_t.numel())
+        if rank in pairs and any(helper_active(pairs, rank, r, world) for r in range(1, world)):
+            recv_sizes[pairs[rank]] = e - b + 1
+        recv_t = ops.new_i32(max(1, sum(recv_sizes)))
+        ops.before_collective()
+        dist.all_to_all_single(recv_t[: sum(recv_sizes)], gap_t[: sum(send_sizes)], recv_sizes, send_sizes)
+        ops.after_collective()
+        if sum(recv_sizes):
+            ops.add_gap(st, recv_t)
+        del recv_t, gap_t
+        if hp is not None:
+            ops.free_block(hp)
     hbs = ops.finish(st, n - e)                                 # [{beg, size, mbv, nbits, psa, psa_hi}] left half, right half
     return merge_ranges(dist, ops, world, rank, n, bounds, hbs)
 
@@ -246,8 +325,9 @@ class HipBlockOps:
     LOOKAHEAD = 1 << 16                                         # text kept behind a block / a searched position for comparisons that read on
 
     def __init__(self, torch, api, text, n, sorter, comm="cuda", max_chains=0, keep_output_on_device=False, merge_rounds=1, force_wide=False,
-                 check_text=None):
+                 check_text=None, helpers=False):
         self.torch, self.api, self.n, self.sorter, self.comm, self.max_chains = torch, api, n, sorter, comm, max_chains
+        self.helpers = helpers                                 # idle ranks stream half of the busy ranks' chunks (helper_of)
         self.text = text if hasattr(text, "window") else WholeText(text, n)
         self.keep_output_on_device = keep_output_on_device
         self.merge_rounds, self.force_wide = merge_rounds, force_wide
@@ -358,7 +438,9 @@ class HipBlockOps:
             d_bbwt = api.DeviceBuffer(bs + 16)
             st.block_i0 = api.merge_bwt(L["bwt"], R["bwt"], ls, rs, L["i0"], R["i0"], st.last_left, st.bvA, d_bbwt)
             st.rank = api.rank_build(d_bbwt, bs)
-            d_bbwt.free()
+            st.bbwt = d_bbwt if self.helpers else None        # a helper rank builds its replica of the rank structure from it
+            if not self.helpers:
+                d_bbwt.free()
             st.gap = api.gap_array(bs, fill=None)
         for hb in (L, R):                                     # BWT and gt bits of the halves are not needed any more
             for key in ("bwt", "gt_begin"):
@@ -383,18 +465,76 @@ class HipBlockOps:
             out.append(int(self.api.initial_ranks(sc, [p])[0]))
         return out
 
-    def stream(self, st, cb, ce, gt_in_t, start_rank, words, first):
+    def stream(self, st, cb, ce, gt_in_t, start_rank, words, first, part=None):
+        """stream the positions part = [lo, hi) of chunk [cb, ce) through st's rank structure (default: the whole chunk).
+        gt_in_t / the returned slice: bit u <-> position ce - u.  hi == ce: start_rank is the exact rank at ce; hi < ce
+        (the left part, its right half is streamed by a helper rank): the start rank is found inside a right context of
+        up to 64 Ki positions (psg_stream_gap_ctx)."""
         api = self.api
-        T = ce - cb
-        keep, gin = self._to_dev(gt_in_t, (T + 31) // 32 + 1)
+        lo, hi = part if part is not None else (cb, ce)
+        T = hi - lo
+        ctx = 0 if hi == ce else min(self.LOOKAHEAD, ce - hi) // 64 * 64
+        assert hi == ce or (ctx >= 64 and (ce - hi) % 64 == 0), "a split chunk needs 64-aligned parts"
+        keep, gin = self._to_dev(gt_in_t, (ce - cb + 31) // 32 + 1)
         _, gout, done = self._slice_out(words)
-        tail = self._text_ptr(cb, ce)
-        nxt = ce + (ce - cb)
-        _, s = api.stream_gap(st.rank, st.block_i0, st.last, tail, T, gin, start_rank, st.gap, gout, self.max_chains, fresh_gap=first)
+        base, _, _ = self.text.window(cb, ce)
+        _, s = api.stream_gap(st.rank, st.block_i0, st.last, base + lo, T, gin + (ce - hi - ctx) // 8, start_rank if hi == ce else -1, st.gap, gout + (ce - hi) // 8,
+                              self.max_chains, right_context=ctx, fresh_gap=first)
         if ce < self.n:
-            self.text.prefetch(ce, min(self.n, nxt))          # the next round's chunk (a TextSource that loads in the background overlaps it with the collective)
+            self.text.prefetch(ce, min(self.n, ce + (ce - cb)))   # the next round's chunk (a TextSource that loads in the background overlaps it with the collective)
         st.last_stats = s
         return done()
+
+    # ---- helper ranks (helper_of)
+    def bits_or(self, a, b):
+        return self.torch.bitwise_or(a, b)
+
+    def block_meta(self, st):
+        return [int(getattr(st, "block_i0", 0)), int(st.last), 0]
+
+    def export_bwt(self, st):
+        """the block BWT as an int32 tensor (padded to whole words)"""
+        bs = st.e - st.b
+        return self._words_from(st.bbwt, 0, (bs + 3) // 4, bs)
+
+    def import_block(self, bwt_t, gb, ge, block_i0, last, start):
+        """replica of block [gb, ge)'s rank structure on this (helper) rank + a gap array of its own"""
+        api = self.api
+
+        class Replica:
+            pass
+        hp = Replica()
+        hp.b, hp.e, hp.block_i0, hp.last, hp.start = gb, ge, block_i0, last, start
+        keep, ptr = self._to_dev(bwt_t, (ge - gb + 3) // 4)
+        hp.rank = api.rank_build(ptr, ge - gb)
+        hp.gap = api.gap_array(ge - gb, fill=None)
+        return hp
+
+    def export_gap(self, hp):
+        """the m + 1 counters of the helper's gap array (32-bit counters: a helper streams fewer than 2^32 suffixes)"""
+        m = hp.e - hp.b
+        assert self.api.download(hp.gap, np.uint32, 4, 4 * ((m + 1 + 3) // 4 * 4))[0] == 0, "excess entries in a helper's gap array"
+        return self._words_from(hp.gap, 0, m + 1)
+
+    def add_gap(self, st, t):
+        """gap[j] += t[j]: the helper's counts join the owner's (no counter comes near 2^32 here: asserted on the helper)"""
+        api = self.api
+        m = st.e - st.b
+        if self.comm == "cuda":
+            mine = self._words_from(st.gap, 0, m + 1)
+            mine += t[: m + 1]
+            api.check(api.lib().psg_d2d(st.gap.ptr, mine.data_ptr(), 4 * (m + 1)))
+            api.sync()
+        else:
+            mine = api.download(st.gap, np.uint32, m + 1)
+            tot = mine.astype(np.uint64) + t[: m + 1].numpy().view(np.uint32)
+            assert tot.max() < (1 << 32)
+            tot32 = np.ascontiguousarray(tot.astype(np.uint32))           # (kept alive across the call)
+            api.check(api.lib().psg_h2d(st.gap.ptr, tot32.ctypes.data, 4 * (m + 1)))
+
+    def free_block(self, hp):
+        hp.rank.free()
+        hp.gap.free()
 
     def finish(self, st, T):
         api = self.api
@@ -405,6 +545,8 @@ class HipBlockOps:
             L["mbv"], L["nbits"] = st.bvA, bs
             return [L, R]
         st.rank.free()
+        if getattr(st, "bbwt", None) is not None:
+            st.bbwt.free()
         mbvL = api.DeviceBuffer(4 * ((bs + T + 31) // 32 + 2))
         mbvR = api.DeviceBuffer(4 * ((rs + T + 31) // 32 + 2))
         api.split_gap(st.gap, st.bvA, ls, rs, T, mbvL, mbvR)

@@ -15,8 +15,8 @@ def _words(bits_u8_packed, words):
 
 
 class OracleBlockOps:
-    def __init__(self, text, merge_rounds=1, force_wide=False):
-        self.merge_rounds, self.force_wide = merge_rounds, force_wide
+    def __init__(self, text, merge_rounds=1, force_wide=False, helpers=False):
+        self.merge_rounds, self.force_wide, self.helpers = merge_rounds, force_wide, helpers
         self.t = np.ascontiguousarray(text, np.uint8)
         self.n = len(self.t)
         self.sa = orc.suffix_array(self.t)
@@ -53,6 +53,7 @@ class OracleBlockOps:
         st.rank = None
         if e < n:
             bbwt, st.bi0 = orc.merge_bwt(lbwt, rbwt, li0, ri0, int(t[mid - 1]), st.bvA)
+            st.bbwt = bbwt
             st.rank = orc.Rank(bbwt)
             st.gap = np.zeros(bs + 1, np.uint64)
         return st
@@ -60,11 +61,46 @@ class OracleBlockOps:
     def start_ranks(self, st, positions):
         return [self._rank_of(st.b, st.e, p) for p in positions]
 
-    def stream(self, st, cb, ce, gt_in_t, start_rank, words, first):
-        gt_in = gt_in_t.numpy().view(np.uint8)
-        g, gto, _ = orc.stream_pass(st.rank, st.bi0, int(self.t[st.e - 1]), self.t, cb, ce, np.ascontiguousarray(gt_in), start_rank)
+    def stream(self, st, cb, ce, gt_in_t, start_rank, words, first, part=None):
+        lo, hi = part if part is not None else (cb, ce)
+        assert (ce - hi) % 64 == 0
+        gt_in = np.ascontiguousarray(gt_in_t.numpy()).view(np.uint8)[(ce - hi) // 8:]          # bit u' = hi - j = u - (ce - hi)
+        init = start_rank if hi == ce else self._rank_of(st.b, st.e, hi)                          # (the device finds it inside a right context)
+        g, gto, _ = orc.stream_pass(st.rank, st.bi0, int(self.t[st.e - 1]), self.t, lo, hi, np.ascontiguousarray(gt_in), init)
         st.gap += g
-        return _words(gto, words)
+        out = np.zeros(words * 4, np.uint8)
+        nb = (hi - lo + 7) // 8
+        out[(ce - hi) // 8: (ce - hi) // 8 + nb] = gto[:nb]
+        return torch.from_numpy(out.view(np.int32).copy())
+
+    # ---- helper ranks
+    def bits_or(self, a, b): return torch.bitwise_or(a, b)
+    def block_meta(self, st): return [int(getattr(st, "bi0", 0)), int(self.t[st.e - 1]), 0]
+
+    def export_bwt(self, st):
+        raw = np.zeros((len(st.bbwt) + 3) // 4 * 4, np.uint8)
+        raw[: len(st.bbwt)] = st.bbwt
+        return torch.from_numpy(raw.view(np.int32).copy())
+
+    def import_block(self, bwt_t, gb, ge, block_i0, last, start):
+        class Replica:
+            pass
+        hp = Replica()
+        hp.b, hp.e, hp.bi0, hp.start = gb, ge, block_i0, start
+        hp.bbwt = np.ascontiguousarray(bwt_t.numpy()).view(np.uint8)[: ge - gb].copy()
+        hp.rank = orc.Rank(hp.bbwt)
+        hp.gap = np.zeros(ge - gb + 1, np.uint64)
+        assert last == int(self.t[ge - 1])
+        return hp
+
+    def export_gap(self, hp):
+        assert hp.gap.max() < (1 << 31)
+        return torch.from_numpy(hp.gap.astype(np.uint32).view(np.int32).copy())
+
+    def add_gap(self, st, t):
+        st.gap += t.numpy().view(np.uint32)[: len(st.gap)].astype(np.uint64)
+
+    def free_block(self, hp): pass
 
     def finish(self, st, T):
         ls, rs, bs = st.mid - st.b, st.e - st.mid, st.e - st.b

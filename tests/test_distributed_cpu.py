@@ -159,7 +159,9 @@ WORKER_BLOCKS = textwrap.dedent("""
         n = len(t)
         # (the short texts also run the merge in three sub-ranges per rank with the high plane of 40-bit partial SAs on the
         #  wire: configs[3]'s form of the exchange)
-        ops = OracleBlockOps(t, merge_rounds=1 if name == "rand1m" else 3, force_wide=name != "rand1m")
+        # ... and with helper ranks (blockdist.helper_of): the high ranks stream half of the low ranks' chunks into gap arrays
+        # of their own, which go home at the end
+        ops = OracleBlockOps(t, merge_rounds=1 if name == "rand1m" else 3, force_wide=name != "rand1m", helpers=name in ("sig4_with_zero", "fib", "rand1m"))
         x0, x1, sa5 = BD.run(dist, ops, world, rank, n)
         assert len(sa5) == 5 * (x1 - x0)
         # every rank contributes its output range; rank 0 assembles the file and compares with the reference's hash
@@ -179,7 +181,7 @@ WORKER_BLOCKS = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5])
 def test_block_per_gpu_schedule_gloo(tmp_path, world):
     """north_star's multi-GPU split (psascan_amd/blockdist.py): one block per rank, one all-gather of the gt slices
     per round, near-to-far chunks with searched start ranks, output-range partitioned merge over slices -- with the

@@ -132,7 +132,7 @@ for case, (mode, n) in enumerate(((extras.MODE_BYTES255, 3_000_017), (extras.MOD
             return r
         if case == 2:
             os.environ["PSG_LOG_WIDE"] = "1"; os.environ["PSG_SM_SB_SHIFT"] = "14"
-        ops = BD.HipBlockOps(torch, api, src, n, sorter, comm="cpu", max_chains=4096, merge_rounds=3, force_wide=True)
+        ops = BD.HipBlockOps(torch, api, src, n, sorter, comm="cpu", max_chains=4096, merge_rounds=3, force_wide=True, helpers=True)   # (+ helper ranks from world = 3 on)
     stats = []
     x0, x1, sa5 = BD.run(dist, ops, world, rank, n, stats)
     os.environ.pop("PSG_LOG_WIDE", None); os.environ.pop("PSG_SM_SB_SHIFT", None)
@@ -146,14 +146,14 @@ for case, (mode, n) in enumerate(((extras.MODE_BYTES255, 3_000_017), (extras.MOD
         whole = np.concatenate([p.numpy()[: int(s)] for p, s in zip(parts, sizes)])
         t = api.download(d_text, np.uint8, n)
         assert np.array_equal(orc.sa5_to_sa(whole), orc.suffix_array(t)), mode
-    assert len(stats) == world - 1 - rank
+    assert len(stats) >= world - 1 - rank                 # (helper ranks stream for their partners as well)
 dist.barrier()
 dist.destroy_process_group()
 print("WORKER_OK", rank)
 """
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_block_per_gpu_schedule_real_kernels(gpu_lib, tmp_path, world):
     """psascan_amd.blockdist with the real kernels: `world` processes share this box's one GPU and talk over gloo
     (the same schedule runs over RCCL on a multi-GPU node).  Three texts: the plain form (whole text resident), and twice
