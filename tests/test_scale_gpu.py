@@ -279,3 +279,30 @@ def test_bench_block_per_gpu_rehearsal(gpu_lib, pieces):
     assert d["n_gpus"] == 3 and d["config"]["blocks"] == 3 and "configs[3] shape" in d["config"]["workload"]
     assert d["property_check"] == {"sampled_adjacent_pairs_out_of_order": 0, "sum_matches_permutation": True}, d["property_check"]
     assert ("40-bit" in d["config"]["workload"]) == pieces
+
+
+def test_python_schedule_and_construct_sa_run_the_same_passes(gpu_lib, tmp_path):
+    """Two orchestrations of ONE schedule: bench.py times psascan_amd/pipeline.py (Python over the C ABI), the drop-in is
+    host/construct_sa (C++ over the same ABI).  On the same text, block size and sorter placement (the device sorter on
+    both sides) they must run the same streaming passes -- per pass the same tail, chain count, chain length and kernel
+    launches -- and write the same bytes."""
+    import os, re, subprocess
+    from psascan_amd import api, extras, pipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, block = 96 << 20, 20_000_003
+    d_text = extras.gen_text(n, extras.MODE_ENGLISH, 0, seed=5)
+    t = api.download(d_text, np.uint8, n)
+    f = tmp_path / "x.bin"
+    t.tofile(f)
+    ram_use = 1_000_000_000
+    stats = []
+    sa5 = pipeline.construct_sa5(None, block, ram_use, extras.DeviceSorter(d_text, n), 0, stats, d_text=d_text, n=n)
+    out = tmp_path / "x.sa5"
+    r = subprocess.run([os.path.join(root, "host", "construct_sa"), "-m", str(ram_use), "--block-size", str(block), "--device-sort", "-v", "-o", str(out), str(f)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4", PSASCAN_PSA_ON_HOST="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.frombuffer(out.read_bytes(), np.uint8), sa5)
+    cli = [tuple(int(x) for x in m) for m in re.findall(r"chains=(\d+) len=(\d+) warmup=\d+ unresolved=\d+ rounds=(\d+)", r.stderr)]
+    mine = [(st.n_chains, st.chain_len, st.rounds) for (_, _, _, st) in stats]
+    assert len(cli) == len(mine) >= 2 * (len(pipeline.block_plan(n, block, ram_use)) - 1), (len(cli), len(mine))
+    assert cli == mine, (cli, mine)
