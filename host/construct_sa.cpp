@@ -436,7 +436,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     opt.device_sort = false;   // the device sorter reads the text up to its end; the leaf merging works through a window per half-block
     fprintf(stderr, "Text stays in host memory: tails are uploaded in chunks of %ld symbols\n\n", (long)opt_in.tail_chunk);
   }
-  Dev d_text(text_on_host ? 16 : (n + 15) / 16 * 16 + 16, true);   // filled further down, while the host threads sort the first leaves
+  Dev d_text(16);                                   // allocated and filled further down, while the host threads sort the first leaves
   Dev tail_buf[2] = {Dev(text_on_host ? opt.tail_chunk + 64 : 16), Dev(text_on_host ? opt.tail_chunk + 64 : 16)};
   const int64_t gt_words = (n + 31) / 32 + 2;
   // gt bits of every position behind the current block w.r.t. its begin (bit n - j), the reference's tail_gt_begin_rev
@@ -822,6 +822,8 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   } joiner{workers, pre_mu, pre_cv, stop_workers};
   if (!text_on_host && n) {
     const double tu = wclock();
+    d_text.alloc((n + 15) / 16 * 16 + 16);
+    CK(psg_memset(d_text.as<uint8_t>() + n / 16 * 16, 0, (n + 15) / 16 * 16 + 16 - n / 16 * 16));   // the padding behind the text
     CK(psg_h2d(d_text.p, text.data(), n));                     // (the leaf sorters are running by now)
     if (g_verbose) fprintf(stderr, "Text on the device after %.2fs (upload %.2fs)\n\n", wclock() - start, wclock() - tu);
   }

@@ -670,6 +670,194 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
   }
 }
 
+// ---- the general merge off its latency chain.  merge_kernel above walks the levels one after the other: the range of
+// level h+1 a tile reads is known only when level h's rank sample and bits have arrived -- 16 dependent round trips per
+// tile at 16 half-blocks (8.9 % of the HBM roofline, profiles/r02_configs2_kernel_stats.csv).  Here a cheap pre-pass
+// walks the levels for every TILE BOUNDARY (one wave per boundary: the 4096-bit group of the position is popcounted by
+// its 64 lanes, merge.hpp:123-158 for one position) and leaves the cursors q_h(t); a tile then knows all its ranges
+// [q_h(t), q_h(t+1)) up front and issues the bit loads of all levels at once, resolves which output slot takes which
+// element of which level in LDS only, and gathers its 8 values per thread in one go: three round trips instead of 2 H.
+#define MCUR_MAXH 128
+__global__ __launch_bounds__(256) void merge_tile_cursor_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, i64 tile0, i64 nb, i64 *cur) {
+  const i64 b = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);          // boundary handled by this wave
+  if (b >= nb) return;
+  const int lane = (int)lane_id();
+  i64 q = std::min(out_begin + (tile0 + b) * MT, out_begin + count);
+  for (int h = 0; h < H; ++h) {
+    if (lane == 0) cur[b * H + h] = q;
+    if (h == H - 1) break;
+    const MergeLevel L = lv[h];
+    i64 ones;
+    if (q >= L.nbits) ones = L.nbits - L.size;                      // everything: all elements of the later half-blocks
+    else {
+      const i64 g = q >> 12, w0 = (g << 7) + 2 * lane;              // this lane's two words of the group
+      u32 part = 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const i64 wb = (w0 + k) << 5;
+        if (wb < q) { u32 w = gload(L.mbv + w0 + k); const i64 nbq = q - wb; if (nbq < 32) w &= (1u << nbq) - 1u; part += __popc(w); }
+      }
+      const u32 inc = wave_incl_scan(part);
+      ones = (i64)gload(L.samp + g) + (i64)__shfl(inc, 63, 64);
+    }
+    q = ones;
+  }
+}
+
+template <bool HI, int OUT>
+__global__ __launch_bounds__(PSG_WG) void merge_kernel_cur(const MergeLevel *lv, int H, i64 out_begin, i64 count, const i64 *cur, i64 tile0, u8 *out, u8 *out_hi) {
+  __shared__ i64 q0s[MCUR_MAXH], q1s[MCUR_MAXH], begs[MCUR_MAXH], nbs[MCUR_MAXH];
+  __shared__ const u32 *mbvs[MCUR_MAXH];
+  __shared__ const u32 *los[MCUR_MAXH];
+  __shared__ const u8 *his[MCUR_MAXH];
+  __shared__ __attribute__((aligned(16))) u16 slotbuf[2][MT];
+  __shared__ u32 info[MT];                   // output slot -> level << 16 | index among the tile's own elements of that level
+  __shared__ u32 wsum[16][4];
+  __shared__ __attribute__((aligned(16))) u32 packed[MT * 5 / 4];
+  const i64 t = blockIdx.x;
+  const i64 x0 = out_begin + (tile0 + t) * MT;
+  const int len = (int)std::min<i64>(MT, out_begin + count - x0);
+  const int e0 = threadIdx.x * MEPT, wave = threadIdx.x >> 6;
+  for (int h = threadIdx.x; h < H; h += PSG_WG) {
+    const MergeLevel L = lv[h];
+    q0s[h] = cur[t * H + h]; q1s[h] = cur[(t + 1) * H + h];
+    begs[h] = L.beg; nbs[h] = L.nbits; mbvs[h] = L.mbv; los[h] = L.lo; his[h] = L.hi;
+  }
+  __syncthreads();
+  int s = 0;
+  bool identity = true;
+  for (int h0 = 0; h0 < H - 1; h0 += 16) {
+    const int ng = std::min(16, H - 1 - h0);
+    u32 bits[16], o[16];
+    int np[16];
+    // the bits of all levels of the group: independent loads, issued together
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      bits[g] = 0; np[g] = 0;
+      if (g < ng) {
+        const int h = h0 + g;
+        const i64 c = q1s[h] - q0s[h];
+        const int n = (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0));
+        np[g] = n;
+        if (n > 0) bits[g] = get_bits(mbvs[h], q0s[h] + e0, n, (nbs[h] + 31) >> 5);
+      }
+    }
+    // ones in front of this thread's positions, for every level of the group: wave scans + one exchange
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const u32 pc = (u32)__popc(bits[g]);
+      const u32 inc = wave_incl_scan(pc);
+      o[g] = inc - pc;
+      if (g < ng && lane_id() == 63) wsum[g][wave] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      if (g < ng) for (int w = 0; w < wave; ++w) o[g] += wsum[g][w];
+    // which output slot does position j of level h stand for?  own elements get their level and their index among the
+    // tile's own elements of that level, survivors move on to the next level (slot numbers only, in LDS)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (g < ng) {
+        const u32 hbits = (u32)(h0 + g) << 16;
+        // the thread's 8 slot numbers in ONE 16-byte LDS read (lane stride 16 bytes: conflict-free; eight 2-byte reads at
+        // that stride were 8-way bank conflicts), then fully unrolled: survivors are appended to the other buffer, own
+        // elements record level | index in the slot's info word
+        const uint4 raw = identity ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)&slotbuf[s][e0];
+        const u32 w4[4] = {raw.x, raw.y, raw.z, raw.w};
+        u32 pos = o[g], zi = (u32)e0 - o[g];
+        const u32 b = bits[g];
+#pragma unroll
+        for (int q = 0; q < MEPT; ++q) {
+          if (q < np[g]) {
+            const u32 slot = identity ? (u32)(e0 + q) : ((w4[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+            if ((b >> q) & 1u) slotbuf[s ^ 1][pos++] = (u16)slot;
+            else info[slot] = hbits | zi++;
+          }
+        }
+        __syncthreads();
+        s ^= 1; identity = false;
+      }
+    }
+  }
+  {   // the last half-block takes what is left, in order
+    const i64 c = q1s[H - 1] - q0s[H - 1];
+    const int n = (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0));
+    const uint4 raw = identity ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)&slotbuf[s][e0];
+    const u32 w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int q = 0; q < MEPT; ++q)
+      if (q < n) {
+        const u32 slot = identity ? (u32)(e0 + q) : ((w4[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+        info[slot] = ((u32)(H - 1) << 16) | (u32)(e0 + q);
+      }
+  }
+  __syncthreads();
+  // ---- the thread's 8 output slots: one gather each, all in flight together
+  const int n = std::max(0, std::min(MEPT, len - e0));
+  u64 v[MEPT];
+#pragma unroll
+  for (int q = 0; q < MEPT; ++q) {
+    v[q] = 0;
+    if (q < n) {
+      const u32 inf = info[e0 + q];
+      const int h = (int)(inf >> 16);
+      const i64 idx = (h == H - 1 ? q0s[h] : q0s[h] - q0s[h + 1]) + (i64)(inf & 0xFFFFu);
+      u64 x = (u64)gload(los[h] + idx);
+      if (HI && his[h]) x |= (u64)gload(his[h] + idx) << 32;
+      v[q] = (u64)begs[h] + x;
+    }
+  }
+  if (OUT != 0) {
+    u32 *o32 = (u32 *)out + (x0 - out_begin) + e0;
+    if (n == MEPT && ((uintptr_t)o32 & 15) == 0) {
+      ((uint4 *)o32)[0] = make_uint4((u32)v[0], (u32)v[1], (u32)v[2], (u32)v[3]);
+      ((uint4 *)o32)[1] = make_uint4((u32)v[4], (u32)v[5], (u32)v[6], (u32)v[7]);
+    } else for (int q = 0; q < n; ++q) o32[q] = (u32)v[q];
+    if (OUT == 2) { u8 *o8 = out_hi + (x0 - out_begin) + e0; for (int q = 0; q < n; ++q) o8[q] = (u8)(v[q] >> 32); }
+    return;
+  }
+  // values -> 40-bit little-endian (types/uint40.hpp:42-104), 8 entries = 10 dwords per thread, through LDS
+  u32 *dst = packed + 10 * threadIdx.x;
+#pragma unroll
+  for (int g4 = 0; g4 < 2; ++g4) {
+    const u32 l0 = (u32)v[4 * g4], l1 = (u32)v[4 * g4 + 1], l2 = (u32)v[4 * g4 + 2], l3 = (u32)v[4 * g4 + 3];
+    const u32 b0 = (u32)(v[4 * g4] >> 32) & 255u, b1 = (u32)(v[4 * g4 + 1] >> 32) & 255u, b2 = (u32)(v[4 * g4 + 2] >> 32) & 255u,
+              b3 = (u32)(v[4 * g4 + 3] >> 32) & 255u;
+    dst[5 * g4 + 0] = l0;
+    dst[5 * g4 + 1] = b0 | (l1 << 8);
+    dst[5 * g4 + 2] = (l1 >> 24) | (b1 << 8) | (l2 << 16);
+    dst[5 * g4 + 3] = (l2 >> 16) | (b2 << 16) | (l3 << 24);
+    dst[5 * g4 + 4] = (l3 >> 8) | (b3 << 24);
+  }
+  __syncthreads();
+  u8 *obase = out + 5 * (x0 - out_begin);
+  const int nbytes = 5 * len, ndw = nbytes >> 2;
+  if (((uintptr_t)obase & 15) == 0) {
+    for (int k = threadIdx.x; k < (ndw >> 2); k += PSG_WG) ((uint4 *)obase)[k] = ((const uint4 *)packed)[k];
+    for (int k = (ndw & ~3) + threadIdx.x; k < ndw; k += PSG_WG) ((u32 *)obase)[k] = packed[k];
+  } else {
+    for (int k = threadIdx.x; k < ndw; k += PSG_WG) ((u32 *)obase)[k] = packed[k];
+  }
+  for (int bb = 4 * ndw + threadIdx.x; bb < nbytes; bb += PSG_WG) obase[bb] = ((const u8 *)packed)[bb];   // ragged end of the last tile
+}
+
+// cursors + merge for the output range [out_begin, out_begin + out_count), in chunks of at most 2^20 tiles
+template <bool HI, int OUT>
+static int launch_merge_cur(int H, const MergeLevel *d_levels, i64 out_begin, i64 out_count, u8 *d_out, u8 *d_out_hi) {
+  const i64 ntiles = cdiv(out_count, MT), CH = (i64)1 << 20;
+  DevBuf cur;
+  if (int rc = cur.alloc((std::min(ntiles, CH) + 1) * H * 8)) return rc;
+  for (i64 t0 = 0; t0 < ntiles; t0 += CH) {
+    const i64 nt = std::min(CH, ntiles - t0);
+    hipLaunchKernelGGL(merge_tile_cursor_kernel, dim3((unsigned)cdiv(nt + 1, 4)), dim3(256), 0, stream(), d_levels, H, out_begin, out_count, t0, nt + 1, cur.as<i64>());
+    hipLaunchKernelGGL((merge_kernel_cur<HI, OUT>), dim3((unsigned)nt), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, cur.as<i64>(), t0, d_out, d_out_hi);
+  }
+  PSG_HIP(hipGetLastError());
+  return 0;
+}
+static bool merge_cur_enabled(int H) { return H >= 3 && H <= MCUR_MAXH && !getenv("PSG_MERGE_CHAIN"); }
+
 // Two half-blocks (one block): out[x] = bit ? psa1[rank1(x)] : psa0[rank0(x)].  No slot compaction in LDS:
 // a thread's 8 output slots take consecutive elements of the two arrays, so its gathers walk two short
 // runs (neighbouring lanes share sectors; the 8 loads are independent and issued together).
@@ -866,6 +1054,9 @@ static int merge_launch(int H, const MergeLevel *d_levels, const MergeLevel &L0,
   if (H == 2 && !getenv("PSG_MERGE_GENERAL")) {   // one block: the two-way kernel
     if (any_hi) hipLaunchKernelGGL(merge2_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
     else hipLaunchKernelGGL(merge2_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), L0, L1, out_begin, out_count, d_out);
+  } else if (merge_cur_enabled(H)) {
+    if (any_hi) return launch_merge_cur<true, 0>(H, d_levels, out_begin, out_count, d_out, nullptr);
+    return launch_merge_cur<false, 0>(H, d_levels, out_begin, out_count, d_out, nullptr);
   } else {
     if (any_hi) hipLaunchKernelGGL(merge_kernel<true>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out, (u8 *)nullptr);
     else hipLaunchKernelGGL(merge_kernel<false>, dim3(grid), dim3(PSG_WG), 0, stream(), d_levels, H, out_begin, out_count, d_out, (u8 *)nullptr);
@@ -881,7 +1072,8 @@ extern "C" int psg_merge_run_u32(const psg_merge_plan_t *p, int64_t out_begin, i
   for (const MergeLevel &L : p->levels) PSG_REQUIRE(!L.hi && L.beg + L.size <= 0x100000000ll, "psg_merge_run_u32: values must fit 32 bits");
   if (out_count == 0) return 0;
   EventTimer tm; tm.start();
-  hipLaunchKernelGGL((merge_kernel<false, 1>), dim3((unsigned)cdiv(out_count, MT)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_out, (u8 *)nullptr);
+  if (merge_cur_enabled(p->H)) { if (int rc = launch_merge_cur<false, 1>(p->H, p->d_levels, out_begin, out_count, (u8 *)d_out, nullptr)) return rc; }
+  else hipLaunchKernelGGL((merge_kernel<false, 1>), dim3((unsigned)cdiv(out_count, MT)), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_out, (u8 *)nullptr);
   PSG_HIP(hipGetLastError());
   tm.stop();
   PSG_HIP(psg::sync_stream());
@@ -898,7 +1090,9 @@ extern "C" int psg_merge_run_planes(const psg_merge_plan_t *p, int64_t out_begin
   for (const MergeLevel &L : p->levels) any_hi |= L.hi != nullptr;
   EventTimer tm; tm.start();
   const unsigned grid = (unsigned)cdiv(out_count, MT);
-  if (any_hi) hipLaunchKernelGGL((merge_kernel<true, 2>), dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_lo, d_hi);
+  if (merge_cur_enabled(p->H)) {
+    if (int rc = any_hi ? launch_merge_cur<true, 2>(p->H, p->d_levels, out_begin, out_count, (u8 *)d_lo, d_hi) : launch_merge_cur<false, 2>(p->H, p->d_levels, out_begin, out_count, (u8 *)d_lo, d_hi)) return rc;
+  } else if (any_hi) hipLaunchKernelGGL((merge_kernel<true, 2>), dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_lo, d_hi);
   else hipLaunchKernelGGL((merge_kernel<false, 2>), dim3(grid), dim3(PSG_WG), 0, stream(), p->d_levels, p->H, out_begin, out_count, (u8 *)d_lo, d_hi);
   PSG_HIP(hipGetLastError());
   tm.stop();

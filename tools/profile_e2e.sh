@@ -11,7 +11,7 @@ grep -E "since start|sufsort|Stream \(|Summary|elapsed|speed|rc=|In-HBM|batched|
 rm -f /tmp/e2e_english_${MIB}.bin.sa5
 cd /tmp && export TMPDIR=/tmp
 OMP_NUM_THREADS=16 PSASCAN_NORMAL_EXIT=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $ROOT/host/construct_sa -v --discard-output /tmp/e2e_english_${MIB}.bin > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
-cd $ROOT
+cd $ROOT; find $O -name "*kernel_trace.csv" -delete
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/${R}_construct_sa_${MIB}mib_kernel_stats.csv
 head -40 $O/${R}_construct_sa_${MIB}mib_kernel_stats.csv
 rm -f /tmp/e2e_english_${MIB}.bin
