@@ -677,7 +677,8 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel(const MergeLevel *lv, int
 // its 64 lanes, merge.hpp:123-158 for one position) and leaves the cursors q_h(t); a tile then knows all its ranges
 // [q_h(t), q_h(t+1)) up front and issues the bit loads of all levels at once, resolves which output slot takes which
 // element of which level in LDS only, and gathers its 8 values per thread in one go: three round trips instead of 2 H.
-#define MCUR_MAXH 128
+#define MCUR_MAXH 48
+#define MCUR_G 8             // levels resolved per group: their bits and scan results live in registers
 __global__ __launch_bounds__(256) void merge_tile_cursor_kernel(const MergeLevel *lv, int H, i64 out_begin, i64 count, i64 tile0, i64 nb, i64 *cur) {
   const i64 b = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);          // boundary handled by this wave
   if (b >= nb) return;
@@ -705,60 +706,71 @@ __global__ __launch_bounds__(256) void merge_tile_cursor_kernel(const MergeLevel
 }
 
 template <bool HI, int OUT>
-__global__ __launch_bounds__(PSG_WG) void merge_kernel_cur(const MergeLevel *lv, int H, i64 out_begin, i64 count, const i64 *cur, i64 tile0, u8 *out, u8 *out_hi) {
-  __shared__ i64 q0s[MCUR_MAXH], q1s[MCUR_MAXH], begs[MCUR_MAXH], nbs[MCUR_MAXH];
-  __shared__ const u32 *mbvs[MCUR_MAXH];
+__global__ __launch_bounds__(PSG_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void merge_kernel_cur(const MergeLevel *__restrict__ lv, int H, i64 out_begin, i64 count, const i64 *__restrict__ cur, i64 tile0, u8 *out, u8 *out_hi) {
+  __shared__ i64 q0s[MCUR_MAXH], begs[MCUR_MAXH];       // per level, for the gather (indexed by each element's level)
   __shared__ const u32 *los[MCUR_MAXH];
   __shared__ const u8 *his[MCUR_MAXH];
-  __shared__ __attribute__((aligned(16))) u16 slotbuf[2][MT];
-  __shared__ u32 info[MT];                   // output slot -> level << 16 | index among the tile's own elements of that level
-  __shared__ u32 wsum[16][4];
-  __shared__ __attribute__((aligned(16))) u32 packed[MT * 5 / 4];
+  // 16 KiB: two slot buffers and the info words while the levels are resolved, the packed 40-bit output afterwards
+  __shared__ __attribute__((aligned(16))) u32 work[MT * 2];
+  u16 (*slotbuf)[MT] = (u16 (*)[MT])work;    // [2][MT]
+  u32 *info = work + MT;                     // output slot -> level << 16 | index among the tile's own elements of that level
+  u32 *packed = work;                        // MT * 5 / 4 words
+  __shared__ u32 wsum[MCUR_G][4];
   const i64 t = blockIdx.x;
   const i64 x0 = out_begin + (tile0 + t) * MT;
   const int len = (int)std::min<i64>(MT, out_begin + count - x0);
-  const int e0 = threadIdx.x * MEPT, wave = threadIdx.x >> 6;
+  const int e0 = threadIdx.x * MEPT, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const i64 wbase = (i64)wave * 64 * MEPT;     // a level with no more than this many positions has nothing for this wave:
+                                               // the ranges only shrink from level to level, so it then skips to the barriers
   for (int h = threadIdx.x; h < H; h += PSG_WG) {
     const MergeLevel L = lv[h];
-    q0s[h] = cur[t * H + h]; q1s[h] = cur[(t + 1) * H + h];
-    begs[h] = L.beg; nbs[h] = L.nbits; mbvs[h] = L.mbv; los[h] = L.lo; his[h] = L.hi;
+    q0s[h] = cur[t * H + h];
+    begs[h] = L.beg; los[h] = L.lo; his[h] = L.hi;
   }
   __syncthreads();
   int s = 0;
   bool identity = true;
-  for (int h0 = 0; h0 < H - 1; h0 += 16) {
-    const int ng = std::min(16, H - 1 - h0);
-    u32 bits[16], o[16];
-    int np[16];
-    // the bits of all levels of the group: independent loads, issued together
+  for (int h0 = 0; h0 < H - 1; h0 += MCUR_G) {
+    const int ng = std::min(MCUR_G, H - 1 - h0);
+    u32 bits[MCUR_G], o[MCUR_G];
+    u32 act = 0;                               // wave-uniform: the levels of the group that have positions for this wave
+    // the bits of all levels of the group: independent loads, issued together (bit 8.. of bits[g]: how many are valid)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      bits[g] = 0; np[g] = 0;
+    for (int g = 0; g < MCUR_G; ++g) {
+      bits[g] = 0;
       if (g < ng) {
-        const int h = h0 + g;
-        const i64 c = q1s[h] - q0s[h];
-        const int n = (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0));
-        np[g] = n;
-        if (n > 0) bits[g] = get_bits(mbvs[h], q0s[h] + e0, n, (nbs[h] + 31) >> 5);
+        const int h = h0 + g;                  // uniform: cursors and level descriptor come through scalar loads
+        const i64 q0 = cur[t * H + h], c = cur[(t + 1) * H + h] - q0;
+        if (c > wbase) {
+          act |= 1u << g;
+          const int n = (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0));
+          if (n > 0) bits[g] = get_bits(lv[h].mbv, q0 + e0, n, (lv[h].nbits + 31) >> 5) | ((u32)n << 8);
+        }
       }
     }
-    // ones in front of this thread's positions, for every level of the group: wave scans + one exchange
+    // ones in front of this thread's positions, for every level of the group: wave scans + one exchange (an idle wave
+    // stands behind every busy one, nobody reads its sum)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const u32 pc = (u32)__popc(bits[g]);
-      const u32 inc = wave_incl_scan(pc);
-      o[g] = inc - pc;
-      if (g < ng && lane_id() == 63) wsum[g][wave] = inc;
+    for (int g = 0; g < MCUR_G; ++g) {
+      o[g] = 0;
+      if ((act >> g) & 1u) {
+        const u32 pc = (u32)__popc(bits[g] & 255u);
+        const u32 inc = wave_incl_scan(pc);
+        o[g] = inc - pc;
+        if (lane_id() == 63) wsum[g][wave] = inc;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 16; ++g)
-      if (g < ng) for (int w = 0; w < wave; ++w) o[g] += wsum[g][w];
+    for (int g = 0; g < MCUR_G; ++g)
+      if ((act >> g) & 1u) for (int w = 0; w < wave; ++w) o[g] += wsum[g][w];
     // which output slot does position j of level h stand for?  own elements get their level and their index among the
     // tile's own elements of that level, survivors move on to the next level (slot numbers only, in LDS)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < MCUR_G; ++g) {
       if (g < ng) {
+       if ((act >> g) & 1u) {
+        const int npg = (int)(bits[g] >> 8);
         const u32 hbits = (u32)(h0 + g) << 16;
         // the thread's 8 slot numbers in ONE 16-byte LDS read (lane stride 16 bytes: conflict-free; eight 2-byte reads at
         // that stride were 8-way bank conflicts), then fully unrolled: survivors are appended to the other buffer, own
@@ -769,20 +781,21 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel_cur(const MergeLevel *lv,
         const u32 b = bits[g];
 #pragma unroll
         for (int q = 0; q < MEPT; ++q) {
-          if (q < np[g]) {
+          if (q < npg) {
             const u32 slot = identity ? (u32)(e0 + q) : ((w4[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
             if ((b >> q) & 1u) slotbuf[s ^ 1][pos++] = (u16)slot;
             else info[slot] = hbits | zi++;
           }
         }
+       }
         __syncthreads();
         s ^= 1; identity = false;
       }
     }
   }
   {   // the last half-block takes what is left, in order
-    const i64 c = q1s[H - 1] - q0s[H - 1];
-    const int n = (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0));
+    const i64 c = cur[(t + 1) * H + H - 1] - cur[t * H + H - 1];
+    const int n = c > wbase ? (int)std::max<i64>(0, std::min<i64>(MEPT, c - e0)) : 0;
     const uint4 raw = identity ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)&slotbuf[s][e0];
     const u32 w4[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
@@ -817,6 +830,7 @@ __global__ __launch_bounds__(PSG_WG) void merge_kernel_cur(const MergeLevel *lv,
     if (OUT == 2) { u8 *o8 = out_hi + (x0 - out_begin) + e0; for (int q = 0; q < n; ++q) o8[q] = (u8)(v[q] >> 32); }
     return;
   }
+  __syncthreads();                             // every info word has been read: the buffer becomes the packed output
   // values -> 40-bit little-endian (types/uint40.hpp:42-104), 8 entries = 10 dwords per thread, through LDS
   u32 *dst = packed + 10 * threadIdx.x;
 #pragma unroll
@@ -856,6 +870,11 @@ static int launch_merge_cur(int H, const MergeLevel *d_levels, i64 out_begin, i6
   PSG_HIP(hipGetLastError());
   return 0;
 }
+// Measured at configs[2]'s 16 half-blocks (profiles/r03_merge_kernel_pmc.txt): neither kernel waits on memory -- an element
+// passes through H/2 levels on average and each is a scan + an LDS round trip, so the time is instruction issue and
+// occupancy.  This kernel issues 0.66x the LDS and 0.8x the VALU instructions of the level-by-level one; at 4 waves per
+// SIMD (34 KiB of LDS, 88 VGPRs) it was no faster, at 8 (19 KiB, 63 VGPRs) it takes 0.61x the time.  PSG_MERGE_CHAIN=1
+// selects the level-by-level kernel, which also serves H > MCUR_MAXH.
 static bool merge_cur_enabled(int H) { return H >= 3 && H <= MCUR_MAXH && !getenv("PSG_MERGE_CHAIN"); }
 
 // Two half-blocks (one block): out[x] = bit ? psa1[rank1(x)] : psa0[rank0(x)].  No slot compaction in LDS:

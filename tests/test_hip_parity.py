@@ -934,8 +934,12 @@ def test_bitcopy_and_popcount(A):
 
 # ------------------------------------------------------------------ final merge (a11, a12)
 @pytest.mark.parametrize("cuts", [[0, 5000], [0, 2500, 5000], [0, 700, 1500, 1501, 2600, 3333, 4100, 5000],
-                                  list(range(0, 5001, 250))])
-def test_merge_vs_oracle(A, cuts):
+                                  list(range(0, 5001, 250)), list(range(0, 5001, 100))])   # 50 half-blocks: beyond the cursor kernel's 48
+@pytest.mark.parametrize("kernel", ["levels", "cursor"])
+def test_merge_vs_oracle(A, cuts, kernel, monkeypatch):
+    """kernel: the one with the tile-cursor pre-pass (default for 3..48 half-blocks) or the level-by-level one"""
+    if kernel == "levels":
+        monkeypatch.setenv("PSG_MERGE_CHAIN", "1")
     rng = np.random.default_rng(13)
     t = rng.integers(0, 3, 5000, dtype=np.uint8)
     n = len(t)
