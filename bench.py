@@ -222,6 +222,8 @@ def setup(args):
     import psascan_amd
     from psascan_amd import api, extras
     L = psascan_amd.lib(local)
+    numa_node = C.c_int(-1)
+    L.psgx_bind_threads_near_device(C.byref(numa_node))      # pinned buffers and copies on the device's socket (a hint)
     if world > 1:
         # everything on ONE explicit stream so RCCL collectives and our kernels are ordered.  (torch's default
         # stream has handle 0, which psg_set_stream takes as "create your own": make a real stream current.)

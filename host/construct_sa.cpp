@@ -409,11 +409,16 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   FILE *out = opt.discard ? nullptr : fopen(out_fn.c_str(), "wb");
   if (!opt.discard && !out) throw std::runtime_error("cannot open output " + out_fn);
   if (n == 0) { if (out) fclose(out); return; }
+  CK(psg_init(0));
+  if (g_verbose) fprintf(stderr, "Device initialised after %.2fs\n", wclock() - start);
+  // everything the host does from here on is copying between pinned buffers, the page cache and the device: keep the
+  // threads (this one and all it starts) on the socket the device hangs on
+  int numa_node = -1;
+  CK(psgx_bind_threads_near_device(&numa_node));
+  if (g_verbose && numa_node >= 0) fprintf(stderr, "Host threads bound to the CPUs of NUMA node %d (the device's)\n", numa_node);
   OutputPrefill prefill;
   if (out && n >= ((int64_t)64 << 20) && !getenv("PSASCAN_NO_PREFILL")) prefill.start(out_fn, 5 * n);
 
-  CK(psg_init(0));
-  if (g_verbose) fprintf(stderr, "Device initialised after %.2fs\n", wclock() - start);
   char devname[256];
   CK(psg_device_name(devname, sizeof devname));
   fprintf(stderr, "Device = %s\n\n", devname);
