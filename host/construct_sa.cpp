@@ -207,17 +207,23 @@ struct DoneHalfBlock {
   Dev psa_dev, psa_hi_dev;        // ... or the partial SA stays in HBM (it fits next to everything else: no PCIe round trip)
   Dev mbv;
   int64_t mbv_bits = 0;           // length of the merge bitvector
-  std::vector<uint32_t> mbv_host; // --hbm-limit: the merge bitvector lives in host memory (psg_mbv_spill) ...
+  psa_host::PsaVec mbv_host;      // the merge bitvector lives in host memory (psg_mbv_spill_begin; not value-initialised: the download is the first touch) ...
   std::vector<uint64_t> mbv_samp; // ... with its rank samples
   void spill_mbv() {
     if (!mbv.p || mbv_bits <= 0) return;
     mbv_host.resize((size_t)psg_mbv_spill_words(mbv_bits));
     mbv_samp.resize((size_t)((mbv_bits + 4095) / 4096 + 1));
-    if (psg_mbv_spill(mbv.as<uint32_t>(), mbv_bits, mbv_host.data(), mbv_samp.data()) != 0) throw std::runtime_error(std::string("psg_mbv_spill: ") + psg_last_error());
-    mbv.release();
+    std::unique_ptr<PendingPsa> P(new PendingPsa());        // in the background, like the partial SAs: the schedule goes on
+    if (psg_mbv_spill_begin(mbv.as<uint32_t>(), mbv_bits, mbv_host.data(), mbv_samp.data(), &P->c_lo) != 0) throw std::runtime_error(std::string("psg_mbv_spill_begin: ") + psg_last_error());
+    mbv.p = nullptr; mbv.bytes = 0;                          // the library frees it when it is drained
+    mbv_pend = std::move(P);
   }
   std::unique_ptr<PendingPsa> pend;   // psa_lo / psa_hi are still being written (settle() before the host reads them)
-  void settle() { if (pend) { pend->wait(); pend.reset(); } }
+  std::unique_ptr<PendingPsa> mbv_pend;   // mbv_host likewise
+  void settle() {
+    if (pend) { pend->wait(); pend.reset(); }
+    if (mbv_pend) { mbv_pend->wait(); mbv_pend.reset(); psg_mbv_spill_finish(mbv_host.data(), mbv_bits); }
+  }
   // device memory is short (or the partial SA has to go to a file): the resident copy moves to host memory
   void to_host() {
     if (!psa_dev.p) return;
@@ -241,9 +247,9 @@ struct DoneHalfBlock {
   DoneHalfBlock(DoneHalfBlock &&o) noexcept { take(o); }
   DoneHalfBlock &operator=(DoneHalfBlock &&o) noexcept { if (this != &o) { drop(); take(o); } return *this; }
   ~DoneHalfBlock() { drop(); }
-  void drop() { pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
+  void drop() { pend.reset(); mbv_pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
   void take(DoneHalfBlock &o) {
-    beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend);
+    beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend); mbv_pend = std::move(o.mbv_pend);
     psa_dev = std::move(o.psa_dev); psa_hi_dev = std::move(o.psa_hi_dev);
     mbv_bits = o.mbv_bits; mbv_host = std::move(o.mbv_host); mbv_samp = std::move(o.mbv_samp);
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
@@ -480,6 +486,26 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
 
   const int64_t n_blocks = (n + max_block_size - 1) / max_block_size;
 
+  // ---- placement plan, from the block layout alone.  The merge bitvector of a half-block has one bit per suffix from its
+  // begin to the end of the text: with H half-blocks that is ~ H/2 * n/8 bytes in all -- quadratic in the number of
+  // blocks (204 GiB for 32 GiB of text in the default 646 MiB blocks), where the reference keeps its gap files on disk
+  // (gap_array.hpp:156-182).  What the plan says does not fit in HBM next to the text, the gt bits and the passes'
+  // temporaries goes to host memory as soon as it is finished: first the partial SAs (the oldest stay), then the
+  // merge bitvectors as well.  The final merge takes either kind from either place.
+  int64_t mbv_total = 0;
+  for (int64_t bid = n_blocks - 1; bid >= 0; --bid) {
+    const int64_t b = max_block_size * bid, e = std::min(b + max_block_size, n);
+    const int64_t ls = e == n ? std::min<int64_t>(e - b, std::max<int64_t>(1, (int64_t)(ram_use / 10))) : std::max<int64_t>(1, (e - b) / 2);
+    mbv_total += (n - b) / 8 + (e < n ? (n - (b + ls)) / 8 : 0) + 64;   // left half: n - b bits; right half (not in the last block): n - mid
+  }
+  const int64_t place_budget = (int64_t)(0.92 * (double)dev_total);
+  const int64_t place_base = (text_on_host ? 0 : n) + (host_tier ? 0 : 8 * gt_words) + 30 * max_block_size + ((int64_t)8 << 30);
+  const bool mbv_on_host = host_tier || place_base + mbv_total > place_budget || getenv("PSASCAN_MBV_ON_HOST") != nullptr;
+  int64_t psa_resident_budget = std::max<int64_t>(0, place_budget - place_base - (mbv_on_host ? 0 : mbv_total)), psa_resident = 0;
+  if (g_verbose || mbv_on_host)
+    fprintf(stderr, "Placement: merge bitvectors %.1f GiB in all -> %s; up to %.1f GiB of partial suffix arrays stay in HBM\n\n", mbv_total / 1073741824.0,
+            mbv_on_host ? "host memory" : "HBM", psa_resident_budget / 1073741824.0);
+
   // ---- --checkpoint DIR.  After every block: the new half-blocks' partial SAs as part files, their merge bitvectors,
   // the gt bits the next block starts from, then a manifest renamed into place -- whatever a crash leaves behind, the
   // manifest names only files that were complete before it was written.  Started again with the same text size, block
@@ -518,6 +544,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     for (; ck_saved < hbs.size(); ++ck_saved) {
       DoneHalfBlock &h = hbs[ck_saved];
       h.keep_part = true;
+      h.settle();
       h.spill(ck_prefix);
       if (h.mbv.p) {
         hostbuf.resize((size_t)h.mbv.bytes);
@@ -576,7 +603,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
           h.mbv.alloc(mv);
           CK(psg_h2d(h.mbv.p, buf.data(), mv));
           h.mbv_bits = n - hb;
-          if (host_tier) h.spill_mbv();
+          if (mbv_on_host) h.spill_mbv();
         }
         struct stat sb;
         if (stat(h.part_file.c_str(), &sb) != 0 || sb.st_size != (off_t)((size_t)hs * (hh ? 5 : 4))) throw std::runtime_error("checkpoint part file missing or short: " + h.part_file);
@@ -1022,10 +1049,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       {
         int64_t in_use = 0, peak = 0, reserved = 0;
         psg_mem_stats(&in_use, &peak, &reserved);
-        const int64_t reserve = 50 * max_block_size + ((int64_t)6 << 30);
-        const bool fits = in_use + reserve < (int64_t)(0.92 * (double)dev_total);
+        const int64_t reserve = 30 * max_block_size + ((int64_t)6 << 30);
+        const int64_t mine = root.psa.bytes + root.psa_hi.bytes;
+        const bool fits = in_use + reserve < place_budget && psa_resident + mine <= psa_resident_budget;   // now, and by the plan
         if (fits && !text_on_host && !opt.spill_psa && !ckpt && !getenv("PSASCAN_PSA_ON_HOST")) {
           H.psa_dev = std::move(root.psa); H.psa_hi_dev = std::move(root.psa_hi);
+          psa_resident += mine;
           return;
         }
       }
@@ -1231,7 +1260,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (last_block) {  // :418-429 -- the left half's gap array is its merge bitvector
       hbL.mbv = std::move(bvA);
       hbL.mbv_bits = bs;
-      if (host_tier) hbL.spill_mbv();
+      if (mbv_on_host) hbL.spill_mbv();
       gt_new.put(n - e, gtA.as<uint32_t>(), rs);
       gt_new.put(n - mid, d_lgt.as<uint32_t>(), ls);
       if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
@@ -1270,7 +1299,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     CK(psg_split_gap(gapB.as<uint32_t>(), bvA.as<uint32_t>(), ls, rs, T, hbL.mbv.as<uint32_t>(), hbR.mbv.as<uint32_t>()));
     log_phase("Compute gaps of half-blocks (device)", t0, bs);
     hbL.mbv_bits = bs + T; hbR.mbv_bits = rs + T;
-    if (host_tier) { const double ts = wclock(); hbL.spill_mbv(); hbR.spill_mbv(); if (g_verbose) fprintf(stderr, "    merge bitvectors to host memory: %.2fs\n", wclock() - ts); }
+    if (mbv_on_host) { const double ts = wclock(); hbL.spill_mbv(); hbR.spill_mbv(); if (g_verbose) fprintf(stderr, "    merge bitvectors to host memory: %.2fs\n", wclock() - ts); }
     if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);

@@ -331,6 +331,11 @@ typedef struct {
  * bits ((nbits + 4095) / 4096 + 1 values, the last one = all ones).  Both may be pageable memory.                  */
 int64_t psg_mbv_spill_words(int64_t nbits);
 int psg_mbv_spill(const uint32_t *d_mbv, int64_t nbits, uint32_t *h_words, uint64_t *h_samp);
+/* the same in the background: h_samp is complete on return, h_words once psg_copy_wait(*out) has returned; d_mbv (from
+ * psg_malloc) is handed to the library and freed when drained.  After the wait, psg_mbv_spill_finish clears the bits
+ * behind nbits (the padding words included).                                                                      */
+int psg_mbv_spill_begin(uint32_t *d_mbv, int64_t nbits, uint32_t *h_words, uint64_t *h_samp, psg_copy_t **out);
+int psg_mbv_spill_finish(uint32_t *h_words, int64_t nbits);
 typedef int (*psg_sink_fn)(void *ctx, const uint8_t *h_sa5, int64_t first_entry, int64_t n_entries);
 typedef struct {
   const uint8_t *d_text;     /* the whole text on the device */

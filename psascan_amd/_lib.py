@@ -126,6 +126,8 @@ SIGNATURES = {
     "psg_merge_leaves": (_int, [C.POINTER(SearchCtxC), _i64, _i64, C.POINTER(_i64), _i64, _vp, _int, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(LeafMergeStatsC)]),
     "psg_mbv_spill_words": (_i64, [_i64]),
     "psg_mbv_spill": (_int, [_vp, _i64, _vp, _vp]),
+    "psg_mbv_spill_begin": (_int, [_vp, _i64, _vp, _vp, C.POINTER(_vp)]),
+    "psg_mbv_spill_finish": (_int, [_vp, _i64]),
     "psg_bitcopy": (_int, [_vp, _i64, _vp, _i64, _i64]),
     "psg_popcount": (_int, [_vp, _i64, C.POINTER(_i64)]),
     "psg_last_kernel_ms": (C.c_double, []),

@@ -1295,6 +1295,28 @@ extern "C" int psg_mbv_spill(const uint32_t *d_mbv, int64_t nbits, uint32_t *h_w
   return 0;
 }
 
+// the same in the background (psg_d2h_begin): the samples are there on return, the words when psg_copy_wait says so; d_mbv
+// (from psg_malloc) is handed over and freed once drained.  psg_mbv_spill_finish then clears what lies behind bit nbits.
+extern "C" int psg_mbv_spill_begin(uint32_t *d_mbv, int64_t nbits, uint32_t *h_words, uint64_t *h_samp, psg_copy_t **out) {
+  PSG_REQUIRE(d_mbv && nbits >= 1 && h_words && h_samp && out, "psg_mbv_spill_begin");
+  const i64 ntiles = cdiv(nbits, TILE_B), nwords = (nbits + 31) / 32;
+  DevBuf samp;
+  int rc;
+  if ((rc = samp.alloc((ntiles + 1) * 8))) return rc;
+  hipLaunchKernelGGL((tile_popc_kernel<false>), dim3((unsigned)ntiles), dim3(PSG_WG), 0, stream(), (const u32 *)d_mbv, nbits, samp.as<u64>());
+  PSG_HIP(hipGetLastError());
+  if ((rc = scan_u64_inplace(samp.as<u64>(), ntiles, samp.as<u64>() + ntiles))) return rc;
+  if ((rc = psg::copy_d2h(h_samp, samp.p, (size_t)(ntiles + 1) * 8))) return rc;
+  return psg_d2h_begin(h_words, d_mbv, nwords * 4, 1, out);
+}
+extern "C" int psg_mbv_spill_finish(uint32_t *h_words, int64_t nbits) {
+  PSG_REQUIRE(h_words && nbits >= 1, "psg_mbv_spill_finish");
+  const i64 nwords = (nbits + 31) / 32;
+  for (i64 w = nwords; w < psg_mbv_spill_words(nbits); ++w) h_words[w] = 0;
+  if (nbits & 31) h_words[nwords - 1] &= (1u << (nbits & 31)) - 1u;
+  return 0;
+}
+
 // number of one bits in front of bit q of a merge bitvector in host memory (samples per 4096 bits + popcount)
 static i64 host_rank1(const u32 *words, const u64 *samp, i64 nbits, i64 q) {
   const i64 ntiles = cdiv(nbits, TILE_B);

@@ -509,6 +509,12 @@ def test_cli_hbm_limit_host_tier(tmp_path, kind):
     assert "check: permutation sum ok, 0 of" in r.stderr and "(on the host" in r.stderr
     assert out.read_bytes() == ref.read_bytes()
     assert np.array_equal(orc.sa5_to_sa(np.frombuffer(out.read_bytes(), np.uint8)), orc.suffix_array(t))
+    # the default placement with only the merge bitvectors planned into host memory (what a text in many small blocks gets:
+    # their total grows with the square of the number of blocks), the partial SAs staying in HBM
+    r = subprocess.run(base + ["--check=300", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=dict(env, PSASCAN_MBV_ON_HOST="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "-> host memory" in r.stderr and "merge bitvectors to host memory" in r.stderr and "Text stays in host memory" not in r.stderr
+    assert out.read_bytes() == ref.read_bytes()
     # a block that needs more than the budget is refused before anything runs
     r = subprocess.run([CLI, "-m", "1G", "--block-size", "4000000", "--hbm-limit", "64Mi", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 1 and "too large for --hbm-limit" in r.stderr
