@@ -204,9 +204,12 @@ def setup(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or args.config == 3:                                # --config 3 on one GPU: the block schedule with a world of one (its full-size block)
         import torch
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("PSASCAN_DIST_BACKEND", "nccl")     # "gloo" + PSASCAN_SHARE_GPU=1: rehearsal on one GPU
         if os.environ.get("PSASCAN_SHARE_GPU") == "1":
             local = 0
@@ -224,7 +227,7 @@ def setup(args):
     L = psascan_amd.lib(local)
     numa_node = C.c_int(-1)
     L.psgx_bind_threads_near_device(C.byref(numa_node))      # pinned buffers and copies on the device's socket (a hint)
-    if world > 1:
+    if dist is not None:
         # everything on ONE explicit stream so RCCL collectives and our kernels are ordered.  (torch's default
         # stream has handle 0, which psg_set_stream takes as "create your own": make a real stream current.)
         shared_stream = torch.cuda.Stream()
@@ -816,6 +819,15 @@ def config_blocks(args, ctx, block):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the result: whatever the libraries below print there (RCCL announces its version on stdout)
+    # goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(res):
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     ctx = setup(args)
     rank, world, local, dist, torch, np, api, extras, L, log = ctx
     cfg = args.config or (2 if world == 1 else 3)     # N > 1: the block-per-GPU schedule; --config 1: the tail-sharded single block
@@ -841,19 +853,19 @@ def main():
                 res["configs1_step"]["workload"] = c1["config"]["workload"]
             except Exception as e:
                 res["configs1_step"] = {"value": None, "note": f"failed: {e!r}"}
-        print(json.dumps(res), flush=True)
-    elif world > 1 and cfg != 1:
+        emit(res)
+    elif cfg == 3 or (world > 1 and cfg != 1):
         args.text = args.text or "dna"                       # BASELINE configs[3]: DNA, 16 GiB blocks, one per GPU
         block = int((args.block_gib or 16.0) * (1 << 30)) // 4096 * 4096
         res = config_blocks(args, ctx, block)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res)
     else:
         args.text = args.text or "bytes"
         res = config1(args, ctx, args.gib or 4.0, args.steps, args.warmup, args.text, True)
         if rank == 0:
-            print(json.dumps(res), flush=True)
-    if world > 1:
+            emit(res)
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -147,6 +147,11 @@ int check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i6
 int search_ranks_launch(const psg_search_ctx *sc, const i64 *d_pos, i64 npos, i64 *d_rank);
 int search_window_check();   // after the search has completed: PSG_EWINDOW if a comparison left the context's text window
 
+// set around a psg_rank_build call: one bit per 3072-position build segment of the symbol-major layout, 0 = nothing will
+// query inside that segment, its entries need not be written (device memory; nullptr = build everything)
+extern const u32 *rank_build_seg_mask;
+constexpr i64 RANK_BUILD_SEG = 3072;
+
 // ---- batched passes: many (block, tail) pairs of one level of the leaf merging in one launch (rank_stream.hip,
 // bits_merge.hip, leaf_tree.hip).  Positions are relative to the begin of the enclosing range; the blocks' BWTs lie
 // at their positions in ONE array over which ONE rank structure is built.

@@ -211,8 +211,26 @@ extern "C" int psg_merge_leaves(const psg_search_ctx *sc, int64_t range_beg, int
     PSG_REQUIRE(m_total < 0xFFFFFFFEll, "psg_merge_leaves: range too large for a 32-bit rank log");
     // ---- rank structure over the level's BWT array
     EventTimer t_rank; t_rank.start();
+    // only the left child of a pair is ranked: positions [beg, beg + size] of the even nodes.  The build segments that lie
+    // wholly inside right children (half of the array from the second level on) are skipped by the fill kernel.
+    DevBuf seg_mask;
+    {
+      const i64 nseg = cdiv(paired_end, RANK_BUILD_SEG), nw = cdiv(nseg, 32);
+      u32 *hm = (u32 *)pinned_buf(15, (size_t)nw * 4);
+      if (!hm) { set_error("psg_merge_leaves: pinned host allocation failed"); return PSG_ENOMEM; }
+      memset(hm, 0, (size_t)nw * 4);
+      for (i64 p = 0; p < P; ++p) {
+        const Node &A = nodes[(size_t)(2 * p)];
+        for (i64 sgm = A.beg / RANK_BUILD_SEG, last = std::min(nseg - 1, (A.beg + A.size) / RANK_BUILD_SEG); sgm <= last; ++sgm) hm[sgm >> 5] |= 1u << (sgm & 31);
+      }
+      if ((rc = seg_mask.alloc(nw * 4))) return rc;
+      PSG_HIP(hipMemcpyAsync(seg_mask.p, hm, (size_t)nw * 4, hipMemcpyHostToDevice, stream()));
+    }
     psg_rank_t *rk = nullptr;
-    if ((rc = psg_rank_build(bwt[cur].as<u8>(), paired_end, 0, &rk))) return rc;
+    rank_build_seg_mask = getenv("PSG_LEAF_FULL_RANK") ? nullptr : seg_mask.as<u32>();
+    rc = psg_rank_build(bwt[cur].as<u8>(), paired_end, 0, &rk);
+    rank_build_seg_mask = nullptr;
+    if (rc) return rc;
     struct RankGuard { psg_rank_t *r; ~RankGuard() { psg_rank_free(r); } } rank_guard{rk};
     t_rank.stop();
     // ---- gap array (shared slots), counter width

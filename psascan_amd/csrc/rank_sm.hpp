@@ -155,7 +155,10 @@ __global__ __launch_bounds__(256) void sm_sb_base_kernel(const u32 *seg_pref, co
 // sbs: segments per superblock; the counts stored in the entries are relative to the superblock start
 template <bool L8>
 __global__ __launch_bounds__(256) void sm_fill_kernel(const u8 *bwt, i64 m, const u64 *t2g, const u32 *seg_pref, const u64 *group_base,
-                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err, i64 sbs) {
+                                                       uint4 *entries, u32 *pool, u32 *pool_cursor, u32 pool_cap, int *err, i64 sbs, const u32 *seg_mask) {
+  // seg_mask (optional): one bit per segment, 0 = no query will ever read this segment's entries (the right children of a
+  // level of psg_merge_leaves are only streamed, never ranked): their entries stay unwritten
+  if (seg_mask && !((seg_mask[blockIdx.x >> 5] >> (blockIdx.x & 31)) & 1u)) return;
   __shared__ __attribute__((aligned(16))) u8 sym[SM_SEG];
   __shared__ __attribute__((aligned(16))) SmPhaseLds P;
   __shared__ u64 t2S[256];

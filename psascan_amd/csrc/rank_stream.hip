@@ -744,6 +744,8 @@ static void launch_build(const u8 *d_bwt, i64 m, const u8 *d_code, u32 *seg_cnt,
                      group_sum, r->d_blocks, r->nblk, r->sb_shift);
 }
 
+namespace psg { const u32 *rank_build_seg_mask = nullptr; }   // see dev_common.hpp
+static_assert(SM_SEG == psg::RANK_BUILD_SEG, "the segment mask is per build segment");
 // Symbol-major layout (rank_sm.hpp).  *fell_back = true: not applicable / did not fit / overflow
 // pool exhausted -- the caller builds a block layout instead.
 static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double budget_bytes, bool allow_list8, bool *fell_back, bool *list8_failed) {
@@ -807,9 +809,9 @@ static int sm_build(psg_rank *r, const u8 *d_bwt, i64 m, const u64 *h, double bu
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(PSG_WG), 0, stream(), group_sum.as<u64>(), ngroups, 256);
   hipLaunchKernelGGL(sm_sb_base_kernel, dim3((unsigned)nsb), dim3(256), 0, stream(), seg_cnt.as<u32>(), group_sum.as<u64>(), sb_segs, sb_d.as<u64>());
   if (list8) hipLaunchKernelGGL(sm_fill_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs);
+                                (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs, psg::rank_build_seg_mask);
   else hipLaunchKernelGGL(sm_fill_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, stream(), d_bwt, m, t2_d.as<u64>(), seg_cnt.as<u32>(), group_sum.as<u64>(),
-                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs);
+                          (uint4 *)entries, (u32 *)pool, misc.as<u32>(), pool_cap, (int *)(misc.as<u32>() + 1), sb_segs, psg::rank_build_seg_mask);
   u32 st[2] = {0, 0};
   hipError_t e4 = hipGetLastError();
   if (e4 != hipSuccess) { set_error(std::string("sm_build: ") + hipGetErrorString(e4)); return fail(PSG_EDEVICE); }

@@ -18,6 +18,7 @@ static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
 static bool g_own_stream = false;
 static bool g_inited = false;
+static int g_device = 0;
 static double g_last_ms = 0;
 
 void set_error(const std::string &s) { g_err = s; }
@@ -423,6 +424,7 @@ int psg_init(int device) {
   }
   PSG_REQUIRE(device >= 0 && device < cnt, "device index out of range");
   PSG_HIP(hipSetDevice(device));
+  g_device = device;
   if (!g_stream) {
     PSG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     g_own_stream = true;
