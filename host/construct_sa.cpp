@@ -1366,7 +1366,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     if (x->out && fwrite(h_sa5, 1, (size_t)(5 * cnt), x->out) != (size_t)(5 * cnt)) { x->ok = false; return 1; }
     return 0;
   };
-  psg_merge_check chk{d_text.as<uint8_t>(), n, opt.check_samples, 12345, 0, 0};
+  psg_merge_check chk{d_text.as<uint8_t>(), n, opt.check_samples, 12345, 0, 0, 0};
   psg_merge_stream_stats ms;
   const int64_t slice = 64LL << 20;  // output entries per slice
   int mrc = psg_merge_stream(desc.data(), (int)desc.size(), std::min(slice, n), opt.check_samples >= 0 && !hcheck.on ? &chk : nullptr, sink, &sctx, &ms);
@@ -1385,8 +1385,9 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   if (opt.check_samples >= 0) {
     const unsigned __int128 nn = (unsigned __int128)n * (unsigned __int128)(n - 1) / 2;
     const bool sum_ok = chk.sum == (uint64_t)nn;
-    fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order%s\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples),
-            hcheck.on ? (hcheck.undecided ? " (on the host; some pairs undecided within 4 Mi symbols)" : " (on the host)") : "");
+    const std::string und = !hcheck.on && chk.undecided_pairs ? ", " + std::to_string((long)chk.undecided_pairs) + " pairs undecided within 16 Mi symbols" : "";
+    fprintf(stderr, "    check: permutation sum %s, %ld of %ld sampled adjacent pairs out of order%s%s\n", sum_ok ? "ok" : "WRONG", (long)chk.bad_pairs, (long)(ms.slices * opt.check_samples),
+            und.c_str(), hcheck.on ? (hcheck.undecided ? " (on the host; some pairs undecided within 4 Mi symbols)" : " (on the host)") : "");
     if (!sum_ok || chk.bad_pairs) throw std::runtime_error("output check failed");
   }
   checkpoint_clear();

@@ -344,6 +344,7 @@ typedef struct {
   uint64_t seed;
   uint64_t sum;              /* out */
   int64_t bad_pairs;         /* out */
+  int64_t undecided_pairs;   /* out: sampled pairs that agree on 2^24 symbols (periodic text) -- not compared to the end, not counted as bad */
 } psg_merge_check;
 typedef struct {
   int64_t slices;

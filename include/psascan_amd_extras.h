@@ -29,6 +29,9 @@ int psgx_sort_halfblock_window(const uint8_t *d_text, int64_t text_begin, int64_
  * adjacent pairs (k, k+1) that are NOT in suffix order.                                      */
 int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples,
                    uint64_t seed, int64_t *bad_pairs, uint64_t *sum);
+/* the same; *undecided_pairs (may be NULL) = sampled pairs that agree on 2^24 symbols and were not followed further */
+int psgx_check_sa5_ex(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples,
+                      uint64_t seed, int64_t *bad_pairs, uint64_t *sum, int64_t *undecided_pairs);
 /* binds all threads of the process to the CPUs of the current device's NUMA node (a placement hint for the pinned
    buffers and the .sa5 writer; never fails).  *node = the node, or -1 if nothing was changed.  PSG_NO_NUMA_BIND=1 disables. */
 int psgx_bind_threads_near_device(int *node);

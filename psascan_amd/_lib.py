@@ -28,7 +28,7 @@ class HbHostDescC(C.Structure):
 
 class MergeCheckC(C.Structure):
     _fields_ = [("d_text", C.c_void_p), ("n", C.c_int64), ("samples_per_slice", C.c_int64), ("seed", C.c_uint64),
-                ("sum", C.c_uint64), ("bad_pairs", C.c_int64)]
+                ("sum", C.c_uint64), ("bad_pairs", C.c_int64), ("undecided_pairs", C.c_int64)]
 
 
 class MergeStreamStatsC(C.Structure):
@@ -142,6 +142,7 @@ EXTRA_SIGNATURES = {
     "psgx_sort_halfblock_window": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
     "psgx_gap_hist": (_int, [_vp, _i64, _i64, _vp]),
     "psgx_check_sa5": (_int, [_vp, _i64, _vp, _i64, _i64, C.c_uint64, C.POINTER(_i64), C.POINTER(C.c_uint64)]),
+    "psgx_check_sa5_ex": (_int, [_vp, _i64, _vp, _i64, _i64, C.c_uint64, C.POINTER(_i64), C.POINTER(C.c_uint64), C.POINTER(_i64)]),
 }
 
 

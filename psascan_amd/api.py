@@ -470,7 +470,7 @@ def merge_stream(half_blocks, slice_entries, sink=None, check_text=None, n=0, sa
     cb = SINK_FN(_sink) if sink is not None else C.cast(None, SINK_FN)
     chk = None
     if check_text is not None:
-        chk = MergeCheckC(_ptr(check_text), n, samples_per_slice, seed, 0, 0)
+        chk = MergeCheckC(_ptr(check_text), n, samples_per_slice, seed, 0, 0, 0)
     st = MergeStreamStatsC()
     rc = lib().psg_merge_stream(arr, H, slice_entries, C.byref(chk) if chk is not None else None, cb, None, C.byref(st))
     if err:

@@ -1419,7 +1419,7 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   pin_lv[0] = (MergeLevel *)pinned_buf(12, 2 * sizeof(MergeLevel) * (size_t)H);
   if (!pin_lv[0]) { set_error("psg_merge_stream: pinned host allocation failed"); return PSG_ENOMEM; }
   pin_lv[1] = pin_lv[0] + H;
-  if (check) { if ((rc = acc.alloc(16))) return rc; PSG_HIP(hipMemsetAsync(acc.p, 0, 16, stream())); }
+  if (check) { if ((rc = acc.alloc(24))) return rc; PSG_HIP(hipMemsetAsync(acc.p, 0, 24, stream())); }
   hipStream_t up = side_stream();
   if (!up) { set_error("psg_merge_stream: cannot create the copy stream"); return PSG_EDEVICE; }
   hipEvent_t ev_up[2] = {event_acquire(), event_acquire()}, ev_dn[2] = {event_acquire(), event_acquire()};
@@ -1532,9 +1532,9 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   PSG_HIP(psg::sync_stream());
   if (result) return result;
   if (check) {
-    u64 h2[2];
-    if ((rc = psg::copy_d2h(h2, acc.p, 16))) return rc;
-    check->sum = h2[0]; check->bad_pairs = (i64)h2[1];
+    u64 h2[3];
+    if ((rc = psg::copy_d2h(h2, acc.p, 24))) return rc;
+    check->sum = h2[0]; check->bad_pairs = (i64)h2[1]; check->undecided_pairs = (i64)h2[2];
   }
   st.total_ms = wall_ms() - w0;
   note_kernel_ms(st.kernel_ms);

@@ -381,6 +381,7 @@ extern "C" int psgx_sort_halfblock(const uint8_t *d_text, int64_t n, int64_t beg
 // ---------------------------------------------------------------------------------------
 // full-size property check of a .sa5 buffer: (a) sum of all entries (mod 2^64) -- equals
 // n(n-1)/2 for a permutation of 0..n-1; (b) `samples` random adjacent pairs are in suffix order.
+// d_acc: three 64-bit accumulators -- sum, pairs out of order, pairs undecided within the comparison budget.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 load_u40(const u8 *p) {
   return (u64)p[0] | ((u64)p[1] << 8) | ((u64)p[2] << 16) | ((u64)p[3] << 24) | ((u64)p[4] << 32);
@@ -400,7 +401,9 @@ __global__ __launch_bounds__(PSG_WG) void sa5_order_kernel(const u8 *text, i64 n
   if (a >= n || b >= n || a == b) { atomicAdd(bad, 1ull); return; }
   i64 budget = (i64)1 << 24;                               // a sampled pair that agrees on 16 Mi symbols is not followed further (periodic text)
   int spent = 0;
-  if (!suffix_less_bounded(text, n, a, b, 0, budget, &spent) && !spent) atomicAdd(bad, 1ull);
+  const bool less = suffix_less_bounded(text, n, a, b, 0, budget, &spent);
+  if (spent) atomicAdd(bad + 1, 1ull);                     // undecided within the budget: reported, not counted as in order
+  else if (!less) atomicAdd(bad, 1ull);
 }
 int psg::check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 count, i64 samples, u64 seed, unsigned long long *d_acc) {
   if (count <= 0) return 0;
@@ -410,16 +413,21 @@ int psg::check_sa5_accumulate(const u8 *d_text, i64 n, const u8 *d_sa5, i64 coun
   return 0;
 }
 
-extern "C" int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples, uint64_t seed,
-                              int64_t *bad_pairs, uint64_t *sum) {
+extern "C" int psgx_check_sa5_ex(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples, uint64_t seed,
+                                 int64_t *bad_pairs, uint64_t *sum, int64_t *undecided_pairs) {
   PSG_REQUIRE(d_text && d_sa5 && bad_pairs && sum && count >= 0, "psgx_check_sa5");
   DevBuf acc;
-  if (int rc = acc.alloc(16)) return rc;
-  PSG_HIP(hipMemsetAsync(acc.p, 0, 16, stream()));
+  if (int rc = acc.alloc(24)) return rc;
+  PSG_HIP(hipMemsetAsync(acc.p, 0, 24, stream()));
   if (int rc = psg::check_sa5_accumulate(d_text, n, d_sa5, count, samples, seed, acc.as<unsigned long long>())) return rc;
-  u64 h[2];
-  if (int rc_ = psg::copy_d2h(h, acc.p, (size_t)(16))) return rc_;
+  u64 h[3];
+  if (int rc_ = psg::copy_d2h(h, acc.p, (size_t)(24))) return rc_;
   PSG_HIP(psg::sync_stream());
   *sum = h[0]; *bad_pairs = (i64)h[1];
+  if (undecided_pairs) *undecided_pairs = (i64)h[2];
   return 0;
+}
+extern "C" int psgx_check_sa5(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, int64_t count, int64_t samples, uint64_t seed,
+                              int64_t *bad_pairs, uint64_t *sum) {
+  return psgx_check_sa5_ex(d_text, n, d_sa5, count, samples, seed, bad_pairs, sum, nullptr);
 }

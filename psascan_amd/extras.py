@@ -92,6 +92,13 @@ def check_sa5(d_text, n, d_sa5, count, samples=1 << 20, seed=7):
     return bad.value, s.value
 
 
+def check_sa5_ex(d_text, n, d_sa5, count, samples=1 << 20, seed=7):
+    """-> (bad_pairs, sum of entries mod 2^64, pairs left undecided after 2^24 equal symbols)."""
+    bad, s, und = C.c_int64(0), C.c_uint64(0), C.c_int64(0)
+    check(lib().psgx_check_sa5_ex(_ptr(d_text), n, _ptr(d_sa5), count, samples, seed, C.byref(bad), C.byref(s), C.byref(und)))
+    return bad.value, s.value, und.value
+
+
 class DeviceSorter:
     """Sorter for psascan_amd.pipeline.construct_sa5 that keeps everything in HBM (prefix-key radix
     sort: texts with short repeats only).  Stands where the host sorter stands; used by the

@@ -919,6 +919,25 @@ def test_vbyte_large_values(A):
     assert np.array_equal(A.download(d_vb, np.uint8, nb), orc.vbyte_encode(vals))
 
 
+def test_output_check_reports_pairs_it_could_not_decide(A):
+    """the sampled order check of --check follows a pair for 2^24 symbols; what agrees that far (periodic text) is counted
+    as undecided -- reported, neither "in order" nor "out of order" -- and a wrong order is still found elsewhere"""
+    import psascan_amd.extras as X
+    n = 17 << 20
+    d_text = A.upload(np.full(n, 97, np.uint8))
+    sa = np.arange(n - 1, -1, -1, dtype=np.int64)                 # a^n: shorter suffixes first
+    sa5 = np.zeros((n, 5), np.uint8)
+    for k in range(5):
+        sa5[:, k] = (sa >> (8 * k)) & 255
+    d_sa5 = A.upload(sa5.reshape(-1))
+    bad, total, und = X.check_sa5_ex(d_text, n, d_sa5, n, samples=2048, seed=3)
+    assert bad == 0 and total == n * (n - 1) // 2
+    assert 0 < und < 2048 // 4                                      # pairs (k, k+1) share k+1 symbols: the last 1/17 of the slots
+    sa5[[5, 6]] = sa5[[6, 5]]                                       # two short suffixes swapped: a decidable pair out of order
+    bad2, _, _ = X.check_sa5_ex(d_text, n, A.upload(sa5.reshape(-1)), 16, samples=64, seed=1)
+    assert bad2 > 0
+
+
 def test_bitcopy_and_popcount(A):
     rng = np.random.default_rng(4)
     src = rng.integers(0, 256, 4000, dtype=np.uint8)
