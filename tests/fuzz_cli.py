@@ -45,7 +45,7 @@ with tempfile.TemporaryDirectory() as d:
         args = ["-m", "1G"]
         if rng.integers(0, 4):
             args += ["--block-size", str(int(rng.integers(2, max(3, n))))]
-        mode = int(rng.integers(0, 5))
+        mode = int(rng.integers(0, 6))
         if mode == 1:
             args += ["--device-sort"]
         if mode == 2:
@@ -54,8 +54,15 @@ with tempfile.TemporaryDirectory() as d:
             args += ["--no-device-merge"]
         if mode == 4:
             args += ["--spill-psa"]
+        if mode == 5:                                      # the host tier: text, gt bits, partial SAs and merge bitvectors in host memory
+            args += ["--hbm-limit", "256Mi", "--tail-chunk", str(int(rng.integers(max(64, n // 40), max(100, n))))]
+            if "--block-size" not in args:                 # (the default block of -m 1G is beyond that budget and refused up front)
+                args += ["--block-size", str(max(2, n))]
+        run_env = dict(env, PSASCAN_MBV_ON_HOST="1") if mode in (0, 4) and rng.integers(0, 3) == 0 else env   # merge bitvectors alone in host memory
         if rng.integers(0, 2):
-            args += ["--leaf-size", str(int(rng.integers(500, 60000))), "--fanout", str(int(rng.integers(2, 9)))]
+            args += ["--leaf-size", str(int(rng.integers(500, 60000)))]
+            if rng.integers(0, 2):                         # the older tree (one pass at a time, F sub-ranges per step); else: a level per launch sequence
+                args += ["--fanout", str(int(rng.integers(2, 9)))]
         if rng.integers(0, 3) == 0:
             args += ["--chains", str(int(rng.integers(1, 5000)))]
         big = n > 2_000_000
@@ -68,7 +75,7 @@ with tempfile.TemporaryDirectory() as d:
         if os.environ.get("FUZZ_DRY"):
             continue
         try:
-            r = subprocess.run([CLI] + args + ["-v", "-o", out, f], input="y\n", capture_output=True, text=True, timeout=300 if big else 120, env=env)
+            r = subprocess.run([CLI] + args + ["-v", "-o", out, f], input="y\n", capture_output=True, text=True, timeout=300 if big else 120, env=run_env)
         except subprocess.TimeoutExpired as ex:
             bad += 1
             t.tofile(f"gpurun_out/fuzz_timeout_{c}.bin")
