@@ -20,7 +20,7 @@ SAs on the device before the timed region.  `end_to_end_cli` times the whole con
 sample; `configs1_step` keeps last round's single-block step (4 GiB uniform bytes) as a secondary figure.
 
 N > 1: north_star's multi-GPU split -- one 4 GiB block per GPU (text = N blocks), systolic rounds with ONE RCCL
-all-gather of the gt slices per round, output-range partitioned merge (psascan_amd/blockdist.py, config_blocks()).
+point-to-point exchange of the gt slices per round, output-range partitioned merge (psascan_amd/blockdist.py, config_blocks()).
 `--config 1` keeps last round's tail-sharded single-block job (rank-log all-to-all, config1()).
 
 Prints ONE JSON line (rank 0).
@@ -669,7 +669,7 @@ def config2(args, ctx, n, block):
 
 def config_blocks(args, ctx, block):
     """N > 1: north_star's multi-GPU split (psascan_amd/blockdist.py) in BASELINE configs[3]'s shape -- DNA, one block of
-    `block` symbols per GPU (16 GiB: half-blocks of 2^33 symbols, 40-bit partial SAs), one all-gather of the gt slices per
+    `block` symbols per GPU (16 GiB: half-blocks of 2^33 symbols, 40-bit partial SAs), one exchange of the gt slices per
     round over RCCL, output-range partitioned merge in sub-ranges.  Weak scaling in the data a GPU holds (text = N blocks).
     No rank holds the whole text: block q is the seeded generator's output for seed 1000 + q, a rank keeps its own block
     (+ look-ahead) and produces the chunk of a round on its device when the round needs it (a real run uploads it from
@@ -796,17 +796,17 @@ def config_blocks(args, ctx, block):
     suff0 = agg["suffixes"] / K
     achieved = A_STREAM * suff0 / kern0 / 1e9 if kern0 else 0.0
     return {
-        "metric": "input MB/s, hot path of the block-per-GPU schedule (local pass A + BWT merge + rank, systolic gap-stream rounds with one gt all-gather each, gap split, output-range partitioned merge)",
+        "metric": "input MB/s, hot path of the block-per-GPU schedule (local pass A + BWT merge + rank, systolic gap-stream rounds with one point-to-point gt exchange each, gap split, output-range partitioned merge)",
         "value": n * K / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u40 integer", "data": "synthetic",
         "config": {"workload": f"configs[3] shape: {n / 2 ** 30:.2f} GiB {args.text} text (seeded, block q = generator seed 1000 + q), {world} blocks of {block / 2 ** 30:.2f} GiB sharded one per GPU "
-                               f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one RCCL all-gather of the gt slices per round"
+                               f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one exchange of the gt slices per round (a slice goes to the left neighbour and, if that one is helped, its helper: RCCL send/recv)"
                                + (f", helper ranks (rank N-1-g streams half of rank g's chunks once its own are done; one BWT hand-over and one gap reduce per pair)" if ops.helpers and world >= 3 else "")
                                + f", merge partitioned by output range in {rounds} sub-ranges per rank",
                    "text_bytes": n, "blocks": world, "block_bytes": block,
                    "resident_per_rank": "own block of text + look-ahead, two chunk buffers, BWT + gt bits of the halves, rank structure, gap array; partial SAs in pinned host memory",
                    "untimed_preparation": "half-block suffix sorts (device, pieces of 2^31 merged with the hot path), the start ranks found by string search while the partial SAs are on the device",
-                   "collectives_per_step": f"{world - 1} all-gathers of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts, {rounds} all-to-alls"},
+                   "collectives_per_step": f"{world - 1} rounds of at most two sends + two receives of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts, {rounds} all-to-alls"},
         "gap_stream_suffixes_per_s": suff / (elapsed / K), "streamed_suffixes_per_step": suff,
         "roofline": {"bound": "hbm", "kernel": "stream_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "traffic_source": "rank 0's launches; no PMC pass for the multi-GPU run", "algorithmic_bytes_per_suffix": A_STREAM,

@@ -7,7 +7,8 @@ shared-GPU rehearsal).  The text is cut into `world` blocks, rank g owns block g
                 merge, rank over the block BWT -- process_block's steps 1-4 (partial_sufsort.hpp:166-500), no
                 communication.  Product: the rank structure of the block, and the block's OWN gt slice: bits
                 [text[j..) > text[b_g..)] for j in (b_g, e_g].
-  rounds        round r = 1 .. world-1: ONE all-gather of the gt slice every rank produced in round r-1, then
+  rounds        round r = 1 .. world-1: ONE exchange of the gt slice every rank produced in round r-1 (point to point: to the
+                left neighbour and, when that one is helped, its helper -- exchange_gt), then
                 rank g streams chunk q = g + r (the text of block q) through its rank structure into its gap array
                 (compute_gap, partial_sufsort.hpp:512-514).  The gt bits it needs -- [text[j..) > text[e_g..)] for
                 j in chunk q -- are exactly what rank g+1 produced one round earlier while streaming the same chunk
@@ -35,6 +36,8 @@ BASELINE configs[3] (128 GiB of DNA, 8 blocks of 16 GiB, half-blocks of 2^33 sym
   * the merge runs in `rounds` sub-ranges of every rank's output range, one all-to-all each, so that the exchange
     buffers are a fraction of the 5 bytes per symbol a rank receives in total.
 """
+import os as _os
+
 import numpy as np
 
 
@@ -77,6 +80,51 @@ def split_point(cb, ce):
     return ce - ((ce - cb) // 2 + 63) // 64 * 64
 
 
+def streams_for(pairs, d, r, world):
+    """the block whose chunk rank d streams (a part of) in round r: its own, the one it helps, or None"""
+    if d + r < world:
+        return d
+    g = next((g for g, h in pairs.items() if h == d), None)
+    return g if g is not None and helper_active(pairs, g, r, world) else None
+
+
+def gt_sources(pairs, x, r, world):
+    """who holds the gt bits block x's chunk of round r is streamed against: rank x+1 produced them one round earlier
+    (round 1: its own slice), and its helper the right half's share if it was at work then"""
+    return [x + 1] + ([pairs[x + 1]] if helper_active(pairs, x + 1, r - 1, world) else [])
+
+
+def exchange_gt(dist, ops, world, rank, pairs, r, prev, words):
+    """The ONE exchange of round r: every slice goes to the ranks that stream against it -- its left neighbour and,
+    when that one is helped, the helper: at most two point-to-point transfers per rank over xGMI (PSASCAN_GT_EXCHANGE=
+    allgather: the older all-gather, G slices to everybody of which one or two are read).  -> {source rank: slice}"""
+    if world == 1:
+        return {}
+    if _os.environ.get("PSASCAN_GT_EXCHANGE", "p2p") == "allgather":
+        gathered = [ops.new_i32(words) for _ in range(world)]
+        ops.before_collective()
+        dist.all_gather(gathered, prev)
+        ops.after_collective()
+        return dict(enumerate(gathered))
+    mine = streams_for(pairs, rank, r, world)
+    need = gt_sources(pairs, mine, r, world) if mine is not None else []
+    got = {src: (prev if src == rank else ops.new_i32(words)) for src in need}
+    p2p = []
+    for d in range(world):
+        x = streams_for(pairs, d, r, world)
+        if d != rank and x is not None and rank in gt_sources(pairs, x, r, world):
+            p2p.append(dist.P2POp(dist.isend, prev, d))
+    for src in need:
+        if src != rank:
+            p2p.append(dist.P2POp(dist.irecv, got[src], src))
+    if p2p:
+        ops.before_collective()
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+        ops.after_collective()
+    return got
+
+
 def run(dist, ops, world, rank, n, stats=None):
     """The whole schedule on this rank.  Returns (x0, x1, sa5 bytes of the output entries [x0, x1))."""
     bounds = block_bounds(n, world)
@@ -113,17 +161,14 @@ def run(dist, ops, world, rank, n, stats=None):
         del recv_t, bwt_t
     prev = st.own_gt
     for r in range(1, world):
-        gathered = [ops.new_i32(words) for _ in range(world)]
-        if world > 1:
-            ops.before_collective()
-            dist.all_gather(gathered, prev)                     # the ONE collective of the round
-            ops.after_collective()
+        gathered = exchange_gt(dist, ops, world, rank, pairs, r, prev, words)   # the ONE exchange of the round
 
         def gt_in_for(x):
             """gt bits of chunk x + r w.r.t. the end of block x: what rank x+1 (and its helper) wrote one round earlier"""
-            t = gathered[x + 1]
-            if helper_active(pairs, x + 1, r - 1, world):
-                t = ops.bits_or(t, gathered[pairs[x + 1]])
+            src = gt_sources(pairs, x, r, world)
+            t = gathered[src[0]]
+            for y in src[1:]:
+                t = ops.bits_or(t, gathered[y])
             return t
         q = rank + r
         if q < world:

@@ -181,23 +181,24 @@ WORKER_BLOCKS = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 4, 5])
-def test_block_per_gpu_schedule_gloo(tmp_path, world):
-    """north_star's multi-GPU split (psascan_amd/blockdist.py): one block per rank, one all-gather of the gt slices
-    per round, near-to-far chunks with searched start ranks, output-range partitioned merge over slices -- with the
+@pytest.mark.parametrize("world,exchange", [(1, "p2p"), (2, "p2p"), (3, "p2p"), (4, "p2p"), (5, "p2p"), (4, "allgather"), (5, "allgather")])
+def test_block_per_gpu_schedule_gloo(tmp_path, world, exchange):
+    """north_star's multi-GPU split (psascan_amd/blockdist.py): one block per rank, one exchange of gt slices per round
+    (point to point: a slice goes to the left neighbour and, when that one is helped, to its helper; or the older
+    all-gather), near-to-far chunks with searched start ranks, output-range partitioned merge over slices -- with the
     oracle standing in for the kernels, the assembled output must hash to the reference's .sa5 for the five seeded
     inputs of tests/golden/golden.json (random bytes, periodic texts, a 4-letter text with zero bytes)."""
-    _run_workers(tmp_path, WORKER_BLOCKS, world)
+    _run_workers(tmp_path, WORKER_BLOCKS, world, {"PSASCAN_GT_EXCHANGE": exchange})
 
 
-def _run_workers(tmp_path, src, world):
+def _run_workers(tmp_path, src, world, extra_env=None):
     script = tmp_path / "worker.py"
     script.write_text(src.format(root=ROOT))
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LOCAL_RANK=str(r), OMP_NUM_THREADS="1")
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for r, p in enumerate(procs):
         try:
