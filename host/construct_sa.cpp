@@ -412,6 +412,16 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   }
   fprintf(stderr, "RAM budget = %lu (%.1fMiB)\nMax block size = %ld (%.1fMiB)\n\n", (unsigned long)ram_use, ram_use / 1048576.0, (long)max_block_size, max_block_size / 1048576.0);
   double start = wclock();
+  if (g_verbose) {   // how long the process existed before this clock started (loader, HIP fat binary registration, mapping the input)
+    double up = 0; unsigned long long st = 0;
+    if (FILE *f = fopen("/proc/uptime", "r")) { if (fscanf(f, "%lf", &up) != 1) up = 0; fclose(f); }
+    if (FILE *f = fopen("/proc/self/stat", "r")) {
+      char buf[1024]; size_t k = fread(buf, 1, sizeof buf - 1, f); buf[k] = 0; fclose(f);
+      const char *p = strrchr(buf, ')');
+      if (p) { int field = 2; for (++p; *p && field < 22; ++p) if (*p == ' ') ++field; if (field == 22) sscanf(p, "%llu", &st); }
+    }
+    if (up > 0 && st > 0) fprintf(stderr, "Process age when the clock starts: %.2fs\n", up - (double)st / (double)sysconf(_SC_CLK_TCK));
+  }
   FILE *out = opt.discard ? nullptr : fopen(out_fn.c_str(), "wb");
   if (!opt.discard && !out) throw std::runtime_error("cannot open output " + out_fn);
   if (n == 0) { if (out) fclose(out); return; }
@@ -1250,7 +1260,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     stream_pass(rankL, L_i0, text.p[(size_t)mid - 1], mid, rs, d_rgt.as<uint32_t>(), initA, gapA.as<uint32_t>(), gtA.as<uint32_t>(), e, gt_cur.dev(),
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}}, &st);
     log_phase("Stream (right half through left half, device)", t0, rs);
-    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
+    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms histogram=%.2fms call=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms, st.hist_ms, st.total_ms);
     rankLg.reset();
     Dev bvA(4 * ((bs + 31) / 32 + 2), true);
     int64_t nb = 0;
@@ -1288,7 +1298,7 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     stream_pass(rankB, block_i0, text.p[(size_t)e - 1], e, T, gt_cur.dev(), 0, gapB.as<uint32_t>(), gt_new.dev(), e, gt_cur.dev(),
                 {PartRef{hbL.beg, hbL.size, &hbL.psa_lo, &hbL.psa_hi, &hbL}, PartRef{hbR.beg, hbR.size, &hbR.psa_lo, &hbR.psa_hi, &hbR}}, &st, &gt_cur, &gt_new);
     log_phase("Stream (tail through block, device)", t0, T);
-    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms);
+    if (g_verbose) fprintf(stderr, "      chains=%ld len=%ld warmup=%ld unresolved=%ld rounds=%ld kernel=%.2fms histogram=%.2fms call=%.2fms\n", (long)st.n_chains, (long)st.chain_len, (long)st.warmup_steps, (long)st.unresolved, (long)st.rounds, st.kernel_ms, st.hist_ms, st.total_ms);
     rankBg.reset();
     gt_new.put(n - e, gtA.as<uint32_t>(), rs);
     gt_new.put(n - mid, d_lgt.as<uint32_t>(), ls);
@@ -1307,7 +1317,12 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   }
   if (inner_passes) {
     fprintf(stderr, "\nIn-HBM merging of host-sorted leaves: %ld passes, %.2f Gi suffixes streamed\n", (long)inner_passes, inner_suffixes / 1073741824.0);
-    if (g_verbose) fprintf(stderr, "    device allocator: %.2fs in psg_malloc, %.2fs in psg_free (host side)\n", g_alloc_seconds, g_free_seconds);
+    if (g_verbose) {
+      double drv = 0; int64_t segs = 0, segb = 0;
+      (void)psgx_arena_stats(&drv, &segs, &segb);
+      fprintf(stderr, "    device allocator: %.2fs in psg_malloc, %.2fs in psg_free (host side); %ld arena segments (%.1f GiB) fetched from the driver in %.2fs\n", g_alloc_seconds, g_free_seconds,
+              (long)segs, segb / 1073741824.0, drv);
+    }
     if (g_verbose && inner_levels) fprintf(stderr, "    batched merging: %ld levels, %.2fs in the calls; kernels (ms): leaves -> nodes %.0f, rank builds %.0f, start-rank search %.0f, stream %.0f, "
                                                    "rank-log histogram %.0f, gap->bitvector %.0f, merge + gt %.0f\n", (long)inner_levels, bt_total / 1e3, bt_prepare, bt_rank, bt_search, bt_stream, bt_hist, bt_bv, bt_merge);
     if (g_verbose) fprintf(stderr, "    seconds: leaf upload %.2f, start-rank search %.2f, rank build %.2f, stream pass %.2f, gap->bitvector %.2f, merge %.2f, BWT/gt from PSA %.2f\n",

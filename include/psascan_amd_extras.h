@@ -35,6 +35,8 @@ int psgx_check_sa5_ex(const uint8_t *d_text, int64_t n, const uint8_t *d_sa5, in
 /* binds all threads of the process to the CPUs of the current device's NUMA node (a placement hint for the pinned
    buffers and the .sa5 writer; never fails).  *node = the node, or -1 if nothing was changed.  PSG_NO_NUMA_BIND=1 disables. */
 int psgx_bind_threads_near_device(int *node);
+/* what the device-memory arena has cost so far: seconds inside hipMalloc for its segments, how many, their bytes */
+int psgx_arena_stats(double *driver_seconds, int64_t *segments, int64_t *bytes);
 /* gap[v] += #{k : log[k] == v}, v in [0,m]; entries 0xFFFFFFFF are ignored; the log is clobbered.
  * (the atomics-free gap update of psg_stream_gap, exposed for tests)                          */
 int psgx_gap_hist(uint32_t *d_log, int64_t nlog, int64_t m, uint32_t *d_gap);

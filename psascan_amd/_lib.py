@@ -139,6 +139,7 @@ EXTRA_SIGNATURES = {
     "psgx_gen_text": (_int, [_vp, _i64, _int, _int, C.c_uint64]),
     "psgx_sort_halfblock": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
     "psgx_bind_threads_near_device": (_int, [C.POINTER(_int)]),
+    "psgx_arena_stats": (_int, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
     "psgx_sort_halfblock_window": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
     "psgx_gap_hist": (_int, [_vp, _i64, _i64, _vp]),
     "psgx_check_sa5": (_int, [_vp, _i64, _vp, _i64, _i64, C.c_uint64, C.POINTER(_i64), C.POINTER(C.c_uint64)]),

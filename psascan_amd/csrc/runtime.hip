@@ -55,6 +55,9 @@ static const size_t BIG = (size_t)1 << 20, GRAN = (size_t)2 << 20, SEG_MAX = (si
 
 static size_t pool_round(size_t b) { return (b + 4095) / 4096 * 4096; }
 static size_t g_in_use = 0, g_peak = 0, g_small_reserved = 0;   // guarded by g_pool_mu
+static double wall_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+static double g_drv_ms = 0;      // time spent in hipMalloc for arena segments, their number and bytes (psgx_arena_stats)
+static i64 g_drv_calls = 0, g_drv_bytes = 0;
 static size_t g_limit = 0;      // psg_set_memory_limit: the library hands out at most this many bytes (0 = what the device has)
 static void note_use(size_t add) { g_in_use += add; if (g_in_use > g_peak) g_peak = g_in_use; }
 
@@ -105,8 +108,10 @@ hipError_t pool_alloc(void **p, size_t bytes) {
     // new segment: at least the request, otherwise doubling the arena up to 8 GiB steps
     size_t seg = std::max(need, std::min(SEG_MAX, std::max((size_t)64 << 20, total)));
     void *base = nullptr;
+    const double t_drv = wall_ms();
     hipError_t e = hipMalloc(&base, seg);
     if (e != hipSuccess && seg > need) { (void)hipGetLastError(); seg = need; e = hipMalloc(&base, seg); }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool_mu); g_drv_ms += wall_ms() - t_drv; g_drv_calls += 1; g_drv_bytes += (i64)seg; }
     if (e != hipSuccess) {   // give everything unused back and retry once
       (void)hipGetLastError();
       pool_trim();
@@ -691,6 +696,13 @@ int psg_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
   }
   if (free_bytes) *free_bytes = (int64_t)f;
   if (total_bytes) *total_bytes = (int64_t)t;
+  return 0;
+}
+int psgx_arena_stats(double *driver_seconds, int64_t *segments, int64_t *bytes) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (driver_seconds) *driver_seconds = g_drv_ms / 1e3;
+  if (segments) *segments = g_drv_calls;
+  if (bytes) *bytes = g_drv_bytes;
   return 0;
 }
 int psg_mem_stats(int64_t *in_use, int64_t *peak_in_use, int64_t *reserved) {
