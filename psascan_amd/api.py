@@ -487,6 +487,28 @@ def mbv_spill(d_mbv, nbits):
     return words, samp
 
 
+class MbvSpill:
+    """psg_mbv_spill_begin / psg_mbv_spill_finish: the rank samples are there at once, the words drain in the background
+    on the library's copy worker; the device buffer is handed to the library.  wait() -> (words, samples)."""
+
+    def __init__(self, d_mbv, nbits):
+        self.nbits = int(nbits)
+        self.words = np.empty(lib().psg_mbv_spill_words(nbits), np.uint32)
+        self.samp = np.zeros((nbits + 4095) // 4096 + 1, np.uint64)
+        h = C.c_void_p()
+        check(lib().psg_mbv_spill_begin(_ptr(d_mbv), self.nbits, self.words.ctypes.data, self.samp.ctypes.data, C.byref(h)))
+        self.h = h.value
+        if hasattr(d_mbv, "ptr"):
+            d_mbv.ptr = None                          # no longer ours
+
+    def wait(self):
+        if self.h:
+            h, self.h = self.h, None
+            check(lib().psg_copy_wait(h))
+            check(lib().psg_mbv_spill_finish(self.words.ctypes.data, self.nbits))
+        return self.words, self.samp
+
+
 def bitcopy(d_dst, dst_bit, d_src, src_bit, nbits):
     check(lib().psg_bitcopy(_ptr(d_dst), dst_bit, _ptr(d_src), src_bit, nbits))
 

@@ -919,6 +919,49 @@ def test_vbyte_large_values(A):
     assert np.array_equal(A.download(d_vb, np.uint8, nb), orc.vbyte_encode(vals))
 
 
+def test_mbv_spill_in_the_background_equals_the_synchronous_one(A):
+    """psg_mbv_spill_begin + psg_copy_wait + psg_mbv_spill_finish leave the same words and rank samples in host memory
+    as psg_mbv_spill, the bits behind nbits cleared (the device buffer carries garbage there)"""
+    rng = np.random.default_rng(5)
+    for nbits in (1, 31, 4096, 4097, 1_000_003):
+        raw = rng.integers(0, 256, (nbits + 31) // 32 * 4 + 16, dtype=np.uint8)
+        w1, s1 = A.mbv_spill(A.upload(raw), nbits)
+        w2, s2 = A.MbvSpill(A.upload(raw), nbits).wait()
+        assert np.array_equal(w1, w2) and np.array_equal(s1, s2)
+        bits = orc.bits(raw, nbits)
+        assert int(s2[-1]) == int(bits.sum()) and np.array_equal(orc.bits(w2.view(np.uint8), nbits), bits)
+        assert not orc.bits(w2.view(np.uint8), len(w2) * 32)[nbits:].any()
+
+
+def test_thread_binding_and_arena_stats(A):
+    """psgx_bind_threads_near_device (in a child process: it re-binds every thread of its process): the CPUs afterwards are
+    a subset of the CPUs before, the reported node is -1 or a node of this host; psgx_arena_stats counts what the arena
+    fetched from the driver"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        import psascan_amd
+        L = psascan_amd.lib(0)
+        before = os.sched_getaffinity(0)
+        node = C.c_int(-7)
+        assert L.psgx_bind_threads_near_device(C.byref(node)) == 0
+        after = os.sched_getaffinity(0)
+        assert after <= before and len(after) > 0, (before, after)
+        assert node.value == -1 or os.path.isdir("/sys/devices/system/node/node%%d" %% node.value), node.value
+        if node.value >= 0:
+            assert after < before or len(before) == len(after)
+        from psascan_amd import api
+        d = api.DeviceBuffer(64 << 20)
+        sec, segs, nbytes = C.c_double(-1), C.c_int64(-1), C.c_int64(-1)
+        assert L.psgx_arena_stats(C.byref(sec), C.byref(segs), C.byref(nbytes)) == 0
+        assert segs.value >= 1 and nbytes.value >= 64 << 20 and sec.value >= 0
+        print("BIND_OK", node.value, len(before), len(after))
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BIND_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_output_check_reports_pairs_it_could_not_decide(A):
     """the sampled order check of --check follows a pair for 2^24 symbols; what agrees that far (periodic text) is counted
     as undecided -- reported, neither "in order" nor "out of order" -- and a wrong order is still found elsewhere"""
