@@ -220,6 +220,23 @@ def test_bench_configs2_shape_reduced(gpu_lib):
     assert d["roofline"]["frac"] > 0.05 and d["streamed_suffixes_per_step"] > 15 * (1 << 30)
 
 
+def test_bench_configs2_full_size(gpu_lib):
+    """BASELINE configs[2] at its full size -- 32 GiB of English-like text, 8 blocks of 4 GiB, 137 G suffixes streamed --
+    once through bench.py's step (about a minute with the device-side preparation): every output slice passes the
+    property check on the device (permutation sum, sampled adjacent pairs against the text) or the step raises."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import gc
+    gc.collect()
+    gpu_lib.psg_trim()                       # the child needs ~250 GiB of the device: give back what this process has cached
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-output-d2h"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["text_bytes"] == 32 << 30 and d["config"]["blocks"] == 8 and d["config"]["half_blocks"] == 16
+    assert d["streamed_suffixes_per_step"] > 120 * (1 << 30) and d["value"] > 0 and "every_step" in d["property_check"]
+
+
 def test_halfblocks_of_more_than_2_pow_32_symbols(gpu_lib, tmp_path):
     """BASELINE configs[3]'s shape in small: a 9 GiB block of DNA, two half-blocks of 4.5 GiB = more than 2^32 suffixes
     each.  construct_sa --device-sort sorts each in three pieces, merges them with the hot path into a partial SA of
