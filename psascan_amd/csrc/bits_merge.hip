@@ -1349,7 +1349,16 @@ extern "C" int psg_merge_stream(const psg_hb_host_desc *hbs, int H, int64_t slic
   psg_merge_plan *plan = nullptr;
   if (int rc = plan_build(dd.data(), H, false, &plan, !host_mbv)) return rc;
   struct PlanGuard { psg_merge_plan *p; ~PlanGuard() { psg_merge_plan_free(p); } } plan_guard{plan};
-  if (host_mbv && slice_entries > ((i64)16 << 20)) slice_entries = (i64)16 << 20;   // a slice carries up to H levels of bits: smaller slices bound the staging
+  if (host_mbv) {
+    // a slice carries the bits of up to H levels: ~ slice/16 bytes per level on average + up to 1.5 KiB of alignment each,
+    // twice (two slots), next to 9 bytes per entry of partial SA pieces and output.  Smaller slices bound the staging --
+    // against the 16 Mi entries that keep the copies long, and against the memory the budget leaves (many small blocks
+    // under psg_set_memory_limit: H in the tens of thousands).
+    if (slice_entries > ((i64)16 << 20)) slice_entries = (i64)16 << 20;
+    const double avail = (double)mem_available();
+    auto staging = [&](i64 se) { return 2.0 * ((double)H * ((double)se / 16.0 + 1600.0) + 9.0 * (double)se + 64.0 * (double)H); };
+    while (slice_entries > MT && staging(slice_entries) > 0.5 * avail) slice_entries = std::max<i64>(MT, slice_entries / 2 / MT * MT);   // (whole merge tiles)
+  }
   const i64 n = plan->n, ns = cdiv(n, slice_entries);
   psg_merge_stream_stats st = {};
   st.slices = ns;
