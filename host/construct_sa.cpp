@@ -101,7 +101,8 @@ static void usage(int status) {
          "                          4096) sampled adjacent pairs per slice in suffix order (extension)\n"
          "      --discard-output    do everything but write the output file (extension)\n"
          "      --spill-psa         partial suffix arrays in part files GAPFILE.psa.* instead of host\n"
-         "                          memory (extension)\n"
+         "                          memory; merge bitvectors that live in host memory (--hbm-limit, or\n"
+         "                          too many blocks for the device) in GAPFILE.mbv.* as well (extension)\n"
          "      --leaf-size=N       half-blocks larger than N (default 32Ki) are cut into leaves of at most N\n"
          "                          symbols that are suffix-sorted on the host and merged on the device\n"
          "      --fanout=F          merge F sub-ranges per step, one pass at a time (default: pairwise, every\n"
@@ -218,6 +219,26 @@ struct DoneHalfBlock {
     mbv.p = nullptr; mbv.bytes = 0;                          // the library frees it when it is drained
     mbv_pend = std::move(P);
   }
+  // --spill-psa with the merge bitvectors in host memory: they go to a file as well ([words][rank samples]) and are
+  // mapped for the merge -- the reference's gap files (gap_array.hpp:156-182), here in the unary form the merge reads
+  std::string mbv_file;
+  void *mbv_map = nullptr;
+  size_t mbv_map_bytes = 0, mbv_file_words = 0;
+  void spill_mbv_file(const std::string &prefix) {
+    if (mbv_host.empty() || !mbv_file.empty()) return;
+    settle();
+    mbv_file = prefix + ".mbv." + std::to_string(beg);
+    mbv_file_words = mbv_host.size();
+    mbv_map_bytes = 4 * mbv_host.size() + 8 * mbv_samp.size();
+    FILE *f = fopen(mbv_file.c_str(), "wb");
+    bool ok = f && fwrite(mbv_host.data(), 4, mbv_host.size(), f) == mbv_host.size() && fwrite(mbv_samp.data(), 8, mbv_samp.size(), f) == mbv_samp.size();
+    if (f) ok = fclose(f) == 0 && ok;
+    if (!ok) throw std::runtime_error("cannot write the merge bitvector file " + mbv_file);
+    psa_host::PsaVec().swap(mbv_host);
+    std::vector<uint64_t>().swap(mbv_samp);
+  }
+  const uint32_t *mbv_w() const { return mbv_map ? (const uint32_t *)mbv_map : (mbv_host.empty() ? nullptr : mbv_host.data()); }
+  const uint64_t *mbv_s() const { return mbv_map ? (const uint64_t *)((const char *)mbv_map + 4 * mbv_file_words) : (mbv_samp.empty() ? nullptr : mbv_samp.data()); }
   std::unique_ptr<PendingPsa> pend;   // psa_lo / psa_hi are still being written (settle() before the host reads them)
   std::unique_ptr<PendingPsa> mbv_pend;   // mbv_host likewise
   void settle() {
@@ -247,11 +268,19 @@ struct DoneHalfBlock {
   DoneHalfBlock(DoneHalfBlock &&o) noexcept { take(o); }
   DoneHalfBlock &operator=(DoneHalfBlock &&o) noexcept { if (this != &o) { drop(); take(o); } return *this; }
   ~DoneHalfBlock() { drop(); }
-  void drop() { pend.reset(); mbv_pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
+  void drop() {
+    if (mbv_map) munmap(mbv_map, mbv_map_bytes);
+    mbv_map = nullptr;
+    if (!mbv_file.empty()) remove(mbv_file.c_str());
+    mbv_file.clear();
+    drop_psa();
+  }
+  void drop_psa() { pend.reset(); mbv_pend.reset(); if (map) munmap(map, map_bytes); map = nullptr; if (!part_file.empty() && !keep_part) remove(part_file.c_str()); part_file.clear(); }
   void take(DoneHalfBlock &o) {
     beg = o.beg; size = o.size; psa_lo = std::move(o.psa_lo); psa_hi = std::move(o.psa_hi); mbv = std::move(o.mbv); pend = std::move(o.pend); mbv_pend = std::move(o.mbv_pend);
     psa_dev = std::move(o.psa_dev); psa_hi_dev = std::move(o.psa_hi_dev);
     mbv_bits = o.mbv_bits; mbv_host = std::move(o.mbv_host); mbv_samp = std::move(o.mbv_samp);
+    mbv_file = std::move(o.mbv_file); o.mbv_file.clear(); mbv_map = o.mbv_map; o.mbv_map = nullptr; mbv_map_bytes = o.mbv_map_bytes; mbv_file_words = o.mbv_file_words;
     part_file = std::move(o.part_file); o.part_file.clear(); part_has_hi = o.part_has_hi; map = o.map; o.map = nullptr; map_bytes = o.map_bytes;
     keep_part = o.keep_part;
   }
@@ -286,6 +315,12 @@ struct DoneHalfBlock {
     psa_host::PsaHiVec().swap(psa_hi);
   }
   void map_back() {
+    if (!mbv_file.empty() && !mbv_map) {
+      int fd = open(mbv_file.c_str(), O_RDONLY);
+      mbv_map = fd >= 0 ? mmap(nullptr, mbv_map_bytes, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
+      if (fd >= 0) close(fd);
+      if (mbv_map == MAP_FAILED) { mbv_map = nullptr; throw std::runtime_error("cannot map the merge bitvector file " + mbv_file); }
+    }
     if (part_file.empty()) return;
     int fd = open(part_file.c_str(), O_RDONLY);
     map_bytes = (size_t)size * (part_has_hi ? 5 : 4);
@@ -1273,7 +1308,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
       if (mbv_on_host) hbL.spill_mbv();
       gt_new.put(n - e, gtA.as<uint32_t>(), rs);
       gt_new.put(n - mid, d_lgt.as<uint32_t>(), ls);
-      if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
+      if (opt.spill_psa) {
+      hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix);
+      if (mbv_on_host && !ckpt) { hbL.spill_mbv_file(opt.gap_prefix); hbR.spill_mbv_file(opt.gap_prefix); }   // (a checkpoint keeps its own copy of them)
+    }
       hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
       std::swap(gt_cur, gt_new);
       end_block(bid);
@@ -1310,7 +1348,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
     log_phase("Compute gaps of half-blocks (device)", t0, bs);
     hbL.mbv_bits = bs + T; hbR.mbv_bits = rs + T;
     if (mbv_on_host) { const double ts = wclock(); hbL.spill_mbv(); hbR.spill_mbv(); if (g_verbose) fprintf(stderr, "    merge bitvectors to host memory: %.2fs\n", wclock() - ts); }
-    if (opt.spill_psa) { hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix); }
+    if (opt.spill_psa) {
+      hbL.spill(opt.gap_prefix); hbR.spill(opt.gap_prefix);
+      if (mbv_on_host && !ckpt) { hbL.spill_mbv_file(opt.gap_prefix); hbR.spill_mbv_file(opt.gap_prefix); }   // (a checkpoint keeps its own copy of them)
+    }
     hbs.push_back(std::move(hbL)); hbs.push_back(std::move(hbR));
     std::swap(gt_cur, gt_new);
     end_block(bid);
@@ -1339,13 +1380,18 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   double t0 = wclock();
   std::sort(hbs.begin(), hbs.end(), [](const DoneHalfBlock &a, const DoneHalfBlock &b) { return a.beg < b.beg; });
   std::vector<psg_hb_host_desc> desc(hbs.size());
+  {
+    int64_t files = 0, bytes = 0;
+    for (const DoneHalfBlock &h : hbs) if (!h.mbv_file.empty()) { ++files; bytes += (int64_t)h.mbv_map_bytes; }
+    if (files && g_verbose) fprintf(stderr, "    %ld merge bitvector files (%.1f MiB) mapped for the merge\n", (long)files, bytes / 1048576.0);
+  }
   for (size_t h = 0; h < hbs.size(); ++h) {
     hbs[h].settle();
     hbs[h].map_back();
     desc[h] = psg_hb_host_desc{hbs[h].beg, hbs[h].size, hbs[h].lo(), hbs[h].hi(), h + 1 < hbs.size() ? hbs[h].mbv.as<uint32_t>() : nullptr,
                                hbs[h].psa_dev.as<uint32_t>(), hbs[h].psa_hi_dev.as<uint8_t>(),
-                               h + 1 < hbs.size() && !hbs[h].mbv_host.empty() ? hbs[h].mbv_host.data() : nullptr,
-                               h + 1 < hbs.size() && !hbs[h].mbv_samp.empty() ? hbs[h].mbv_samp.data() : nullptr};
+                               h + 1 < hbs.size() ? hbs[h].mbv_w() : nullptr,
+                               h + 1 < hbs.size() ? hbs[h].mbv_s() : nullptr};
   }
   // --check with the text in host memory: the same property check on the host (sum of all entries, sampled adjacent
   // pairs compared in the memory-mapped text), slice by slice as the output arrives
@@ -1415,7 +1461,10 @@ static void run(const std::string &text_fn, const std::string &out_fn, uint64_t 
   fprintf(stderr, "\n\nComputation finished. Summary:\n  elapsed time: %.2fs (%.4fs/MiB)\n  speed: %.2fMiB/s\n", total, total / (n / 1048576.0), (n / 1048576.0) / total);
   // Everything is written and closed.  Leave now: unwinding would hand 4-5 bytes per symbol of partial SAs back to the
   // C library page by page and then run the HIP runtime's teardown of the device arena -- ten seconds after a 32 GiB run.
-  for (DoneHalfBlock &h : hbs) if (!h.part_file.empty() && !h.keep_part) remove(h.part_file.c_str());
+  for (DoneHalfBlock &h : hbs) {
+    if (!h.part_file.empty() && !h.keep_part) remove(h.part_file.c_str());
+    if (!h.mbv_file.empty()) remove(h.mbv_file.c_str());
+  }
   fflush(stdout); fflush(stderr);
   if (getenv("PSASCAN_NORMAL_EXIT")) return;      // under a profiler: its tool library writes its files at a regular exit
   _exit(EXIT_SUCCESS);

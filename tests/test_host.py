@@ -515,6 +515,14 @@ def test_cli_hbm_limit_host_tier(tmp_path, kind):
     assert r.returncode == 0, r.stderr[-3000:]
     assert "-> host memory" in r.stderr and "merge bitvectors to host memory" in r.stderr and "Text stays in host memory" not in r.stderr
     assert out.read_bytes() == ref.read_bytes()
+    # the same budget with --spill-psa: partial SAs AND merge bitvectors in files next to the gap file prefix, mapped for
+    # the merge (the reference's part files and gap files: io/distributed_file.hpp, gap_array.hpp:156-182); gone afterwards
+    g = tmp_path / "gapdir"
+    g.mkdir()
+    r = subprocess.run(base + ["--hbm-limit", "96Mi", "--spill-psa", "-g", str(g / "x"), "--check=300", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "merge bitvector files" in r.stderr and "mapped for the merge" in r.stderr
+    assert out.read_bytes() == ref.read_bytes() and list(g.iterdir()) == []
     # a block that needs more than the budget is refused before anything runs
     r = subprocess.run([CLI, "-m", "1G", "--block-size", "4000000", "--hbm-limit", "64Mi", "-o", str(out), str(f)], input="y\n", capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 1 and "too large for --hbm-limit" in r.stderr

@@ -264,10 +264,11 @@ def test_halfblocks_of_more_than_2_pow_32_symbols(gpu_lib, tmp_path):
 
 
 def test_all_modes_write_the_same_sa5(gpu_lib):
-    """256 MiB of English-like text in 6 blocks through construct_sa in six modes -- default (host leaves merged on the
+    """256 MiB of English-like text in 6 blocks through construct_sa in seven modes -- default (host leaves merged on the
     device in batches), --text-on-host (tails in chunks, leaves through a text window), --device-sort, --spill-psa +
     --checkpoint, --no-device-merge (half-blocks sorted whole on host threads), --hbm-limit (a device budget of ~60 bytes per
-    block symbol: text, gt bits, partial SAs and merge bitvectors in host memory): the .sa5 files are byte-identical (the
+    block symbol: text, gt bits, partial SAs and merge bitvectors in host memory), and that budget with --spill-psa (partial
+    SAs and merge bitvectors in files, mapped for the merge): the .sa5 files are byte-identical (the
     first of them is what the reference's hashes pin at smaller sizes, tests/test_host.py)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

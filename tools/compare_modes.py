@@ -18,7 +18,9 @@ block = str(n // 5 + 12345)
 modes = {"default": [], "text-on-host": ["--text-on-host", "--tail-chunk", str(n // 7)], "device-sort": ["--device-sort"],
          "spill+checkpoint": ["--spill-psa", "--checkpoint", "/tmp/cmp_ck"], "no-device-merge": ["--no-device-merge"],
          # the external-memory schedule: a device budget of ~60 bytes per block symbol -- text, gt bits, partial SAs and merge bitvectors in host memory
-         "hbm-limit": ["--hbm-limit", str(max(64 << 20, 60 * (n // 5 + 12345))), "--tail-chunk", str(n // 7)]}
+         "hbm-limit": ["--hbm-limit", str(max(64 << 20, 60 * (n // 5 + 12345))), "--tail-chunk", str(n // 7)],
+         # ... and with the partial SAs and the merge bitvectors in files (mapped for the merge): only the gt bits stay in host memory
+         "hbm-limit+files": ["--hbm-limit", str(max(64 << 20, 60 * (n // 5 + 12345))), "--tail-chunk", str(n // 7), "--spill-psa", "-g", f + ".gap"]}
 hashes = {}
 for name, extra in modes.items():
     out = f + "." + name.replace("+", "_") + ".sa5"
