@@ -1118,6 +1118,49 @@ def test_merge_high_byte(A):
     assert list(got) == [13, 2 ** 39 + 1, 2 ** 32 + 15, 2 ** 39, 17]
 
 
+@pytest.mark.parametrize("kernel", ["levels", "cursor"])
+@pytest.mark.parametrize("cuts", [[0, 900, 2500, 3600, 5000], list(range(0, 5001, 200))])
+def test_merge_high_planes_many_half_blocks(A, cuts, kernel, monkeypatch):
+    """the general merge kernels with high planes in play (HI = true): values of up to 40 bits from the planes and from the
+    half-blocks' offsets, 4 and 25 half-blocks, some without a high plane; whole output, a sub-range, and both planes of
+    psg_merge_run_planes against the oracle's merge of the same numbers"""
+    if kernel == "levels":
+        monkeypatch.setenv("PSG_MERGE_CHAIN", "1")
+    rng = np.random.default_rng(31)
+    n = cuts[-1]
+    t = rng.integers(0, 4, n, dtype=np.uint8)
+    sa = orc.suffix_array(t)
+    isa = orc.inverse(sa)
+    hbs, begs, sizes, psas, gaps = [], [], [], [], []
+    for h in range(len(cuts) - 1):
+        b, e = cuts[h], cuts[h + 1]
+        psa, _, _, _ = orc.partial_sa(t, sa, isa, b, e, want_gt=False)
+        val = psa.astype(np.uint64) + (np.uint64(rng.integers(0, 200)) << np.uint64(32)) * np.uint64(h % 3 != 1)   # every third half-block: no high plane
+        val[:: 7] += np.uint64(1) << np.uint64(32)
+        if h % 3 == 1:
+            val = psa.astype(np.uint64)
+        g = np.bincount(np.searchsorted(np.sort(isa[b:e]), isa[e:n]), minlength=e - b + 1).astype(np.uint64)
+        mbv = None
+        if e < n:
+            bv, nb = orc.gap_to_bitvector(g, e - b)
+            mbv = A.upload(bv[: (nb + 7) // 8])
+        beg = b + ((2 * h) << 32)                  # (half-block offsets are non-decreasing)
+        begs.append(beg); sizes.append(e - b); psas.append(val); gaps.append(g if e < n else None)
+        hbs.append({"beg": beg, "size": e - b, "psa_lo": A.upload((val & np.uint64(0xFFFFFFFF)).astype(np.uint32)),
+                    "psa_hi": None if h % 3 == 1 else A.upload((val >> np.uint64(32)).astype(np.uint8)), "mbv": mbv})
+    want = orc.merge(begs, sizes, psas, gaps)
+    assert np.array_equal(A.download(A.merge_half_blocks(hbs), np.uint8, 5 * n), want)
+    plan = A.MergePlan(hbs)
+    d_part = A.DeviceBuffer(5 * 2049 + 8)
+    plan.run(1500, 2049, d_part)
+    assert np.array_equal(A.download(d_part, np.uint8, 5 * 2049), want[5 * 1500: 5 * (1500 + 2049)])
+    d_lo, d_hi = A.DeviceBuffer(4 * n + 16), A.DeviceBuffer(n + 16)
+    A.merge_run_planes(plan, 0, n, d_lo, d_hi)
+    w = orc.sa5_to_sa(want)
+    assert np.array_equal(A.download(d_lo, np.uint32, n).astype(np.int64), w & 0xFFFFFFFF)
+    assert np.array_equal(A.download(d_hi, np.uint8, n).astype(np.int64), w >> 32)
+
+
 # ------------------------------------------------------------------ whole path vs the reference's hashes
 def oracle_sorter(sa, isa):
     def sorter(text, beg, end, gt_tail):
