@@ -56,8 +56,8 @@ with tempfile.TemporaryDirectory() as d:
             args += ["--spill-psa"]
         if mode == 5:                                      # the host tier: text, gt bits, partial SAs and merge bitvectors in host memory
             args += ["--hbm-limit", "256Mi", "--tail-chunk", str(int(rng.integers(max(64, n // 40), max(100, n))))]
-            if "--block-size" not in args:                 # (the default block of -m 1G is beyond that budget and refused up front)
-                args += ["--block-size", str(max(2, n))]
+            if "--block-size" not in args:                 # (the default block of -m 1G is beyond that budget and refused up front:
+                args += ["--block-size", str(max(2, min(n, 4_000_000)))]   # ~50 bytes of device memory per block symbol)
         run_env = dict(env, PSASCAN_MBV_ON_HOST="1") if mode in (0, 4) and rng.integers(0, 3) == 0 else env   # merge bitvectors alone in host memory
         if rng.integers(0, 2):
             args += ["--leaf-size", str(int(rng.integers(500, 60000)))]
