@@ -738,13 +738,26 @@ def config_blocks(args, ctx, block):
     api.sync()
     log(f"rank 0 prepared its block of {n / 2 ** 30:.2f} GiB {args.text} text in {time.time() - t0:.1f}s ({'40-bit' if wide else '32-bit'} partial SAs, merge in {rounds} rounds)")
 
+    # helper ranks (blockdist.helper_of) cost the helper a replica of its partner's rank structure and BWT, a gap array of
+    # its own (4 bytes per block symbol) and the two tensors of the gap reduce: on when that fits next to the rank's own
+    # ~12 bytes per block symbol of resident state (PSASCAN_HELPERS=1 / 0 forces it).  At configs[3]'s 16 GiB blocks it does
+    # not (191 + 221 GiB): the run is then the plain systolic schedule.
+    henv = os.environ.get("PSASCAN_HELPERS", "auto")
+    if henv == "auto":
+        rank_bps = {"dna": 0.8, "english": 4.0}.get(args.text, 8.5)
+        own = block * (1 + 2 + 1 + 0.25 + rank_bps + 4 + 1.7 + 1.2)
+        extra = block * (rank_bps + 1 + 4 + 4 + 4)
+        helpers = own + extra <= 0.85 * api.device_memory()[1]
+    else:
+        helpers = henv != "0"
+
     def replay(text, hb, he, gt_tail):
         return dict(prepared[(hb, he)][1])
     # tensors handed to the collectives: CUDA tensors with RCCL; CPU tensors in the gloo rehearsal (PSASCAN_COMM=cuda
     # rehearses the CUDA-tensor code path over gloo)
     ops = BD.HipBlockOps(torch, api, src, n, replay, comm=comm, max_chains=args.max_chains, keep_output_on_device=True, merge_rounds=rounds,
                          force_wide=any(ent.get("psa_hi") is not None for (_, ent) in prepared.values()),   # (rehearsals force pieces: PSASCAN_TEST_PIECE_MAX)
-                         helpers=os.environ.get("PSASCAN_HELPERS", "1") != "0")
+                         helpers=helpers)
     wide = wide or ops.force_wide
     agg = {"suffixes": 0, "kernel_ms": 0.0, "stream_ms": 0.0, "launches": 0}
 
@@ -803,7 +816,7 @@ def config_blocks(args, ctx, block):
                                f"({'40-bit partial SAs in two planes' if wide else '32-bit partial SAs'}), {world - 1} rounds, one exchange of the gt slices per round (a slice goes to the left neighbour and, if that one is helped, its helper: RCCL send/recv)"
                                + (f", helper ranks (rank N-1-g streams half of rank g's chunks once its own are done; one BWT hand-over and one gap reduce per pair)" if ops.helpers and world >= 3 else "")
                                + f", merge partitioned by output range in {rounds} sub-ranges per rank",
-                   "text_bytes": n, "blocks": world, "block_bytes": block,
+                   "text_bytes": n, "blocks": world, "block_bytes": block, "helper_ranks": bool(ops.helpers and world >= 3),
                    "resident_per_rank": "own block of text + look-ahead, two chunk buffers, BWT + gt bits of the halves, rank structure, gap array; partial SAs in pinned host memory",
                    "untimed_preparation": "half-block suffix sorts (device, pieces of 2^31 merged with the hot path), the start ranks found by string search while the partial SAs are on the device",
                    "collectives_per_step": f"{world - 1} rounds of at most two sends + two receives of {BD.slice_words(bounds) * 4} B per rank, {2 * world - 1} broadcasts, {rounds} all-to-alls"},
